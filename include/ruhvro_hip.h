@@ -1,0 +1,121 @@
+/* ruhvro_hip.h -- C ABI of the MI355X-native Avro -> Arrow direct-decode engine.
+ *
+ * Drop-in boundary for ONE path of Tyler-Sch/pyruhvro: the chunked direct
+ * decode that `pyruhvro.deserialize_array_threaded` reaches.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repository root).  Plain pointers and sizes only; no torch / pybind types.
+ *
+ * Conventions: functions returning int return 0 on success; on failure they
+ * return non-zero and, when `err` is non-NULL, store a malloc'd NUL-terminated
+ * message in *err (release with rh_free_string).  Decode errors carry exactly
+ * the reference's message text (ruhvro/src/fast_decode.rs:575,591,634,646,
+ * 849,866,874,884,898,906,910); the Python layer maps them to ValueError as
+ * src/lib.rs:25-27 does.  All functions are thread-safe; a compiled schema
+ * may be shared by concurrent calls.
+ */
+#ifndef RUHVRO_HIP_H
+#define RUHVRO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include "arrow_c_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_ABI_VERSION 1
+
+/* error classes (return codes) */
+#define RH_OK 0
+#define RH_ERR_SCHEMA 1      /* schema JSON invalid / outside the direct-decode subset */
+#define RH_ERR_DECODE 2      /* malformed Avro datum: reference message text in *err  */
+#define RH_ERR_RUNTIME 3     /* HIP / allocation failure                               */
+#define RH_ERR_ARGUMENT 4
+
+typedef struct rh_schema rh_schema;
+
+/* Replaces ruhvro::deserialize::parse_schema (ruhvro/src/deserialize.rs:18-20)
+ * plus the per-call schema work of the fast path: the is_supported gate
+ * (ruhvro/src/fast_decode.rs:38-61), to_arrow_schema
+ * (ruhvro/src/schema_translate.rs:19-37) and decoder-tree construction
+ * (fast_decode.rs:176-414).  The result is immutable; cache it by schema
+ * string as src/lib.rs:39-54 does. */
+rh_schema* rh_schema_compile(const char* json, size_t len, char** err);
+void rh_schema_free(rh_schema* s);
+
+/* Arrow schema of the produced batches, exported as a "+s" struct schema whose
+ * children are the batch columns (what arrow-rs hands pyarrow at
+ * src/lib.rs:70,88 through its pyarrow FFI).  Caller releases out->release. */
+int rh_schema_export(const rh_schema* s, struct ArrowSchema* out);
+
+/* clamp_chunks (ruhvro/src/deserialize.rs:53-55): number of batches a decode
+ * of n records with `num_chunks` returns. */
+uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks);
+
+typedef struct {
+  int32_t device;        /* HIP device ordinal; -1 = current device          */
+  int32_t flags;         /* reserved, 0                                      */
+  void* stream;          /* hipStream_t to launch on; NULL = engine's stream */
+} rh_opts;
+
+typedef struct {
+  uint64_t records;
+  uint64_t input_bytes;      /* Avro payload bytes                               */
+  uint64_t output_bytes;     /* Arrow buffer bytes produced (all chunks)         */
+  uint32_t chunks;
+  uint32_t blocks;           /* workgroups per kernel launch                     */
+  float pack_ms;             /* host gather of the record slices                 */
+  float h2d_ms;
+  float size_kernel_ms;      /* k_size   (walk 1: per-record sizes)              */
+  float scan_kernel_ms;      /* k_scan   (segmented exclusive scans)             */
+  float emit_kernel_ms;      /* k_emit   (walk 2: column materialisation)        */
+  float d2h_ms;
+  float total_ms;
+} rh_stats;
+
+/* Replaces ruhvro::deserialize::per_datum_deserialize_threaded
+ * (ruhvro/src/deserialize.rs:76-121; single-chunk form per_datum_deserialize,
+ * deserialize.rs:25-30, is num_chunks = 1).  Input: n record slices owned by
+ * the caller for the duration of the call (src/lib.rs:29-33,84).  Output:
+ * out_chunks[0..*out_k) are struct arrays (one per chunk, chunk boundaries of
+ * deserialize.rs:57-68, order preserved) in host memory; the caller provides
+ * room for rh_clamp_chunks(n, num_chunks) entries and releases each through
+ * ArrowArray.release.  The first malformed record (lowest index) aborts the
+ * call with its message, as the in-order join at deserialize.rs:115-119 does. */
+int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* lens,
+              uint64_t n, uint64_t num_chunks, const rh_opts* opts,
+              struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err);
+
+/* Same, for input already packed the way the reference packs it internally
+ * (BinaryArray, deserialize.rs:90): one contiguous buffer + n+1 offsets. */
+int rh_decode_packed(const rh_schema* s, const uint8_t* data, const uint64_t* offsets,
+                     uint64_t n, uint64_t num_chunks, const rh_opts* opts,
+                     struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err);
+
+/* Device-resident form of the same path: `d_data`/`d_offsets` (u64[n+1]) live
+ * in HBM (d_data 16-byte aligned, data_len = offsets[n]), the Arrow buffers are
+ * produced in HBM and stay there.  This is the kernel-only path bench.py times.
+ * The result owns its device memory. */
+typedef struct rh_device_result rh_device_result;
+int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offsets,
+                     uint64_t data_len, uint64_t n, uint64_t num_chunks, const rh_opts* opts,
+                     rh_device_result** out, rh_stats* stats, char** err);
+uint32_t rh_device_result_chunks(const rh_device_result* r);
+/* Exact (unpadded) Arrow buffer bytes the call produced, all chunks. */
+uint64_t rh_device_result_output_bytes(const rh_device_result* r);
+/* Arrow C Device Data Interface view of chunk i (device_type ARROW_DEVICE_ROCM);
+ * valid until rh_device_result_free; release the view through array.release. */
+int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDeviceArray* out);
+/* Copy the chunks to host memory (same form rh_decode returns). */
+int rh_device_result_to_host(rh_device_result* r, struct ArrowArray* out_chunks, char** err);
+void rh_device_result_free(rh_device_result* r);
+
+void rh_free_string(char* s);
+int rh_abi_version(void);
+/* Number of visible HIP devices (0 when no GPU / driver); never throws. */
+int rh_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

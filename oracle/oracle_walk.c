@@ -37,7 +37,6 @@ static void by_reserve(bytes_t *b, size_t extra) {
   size_t nc = b->cap ? b->cap * 2 : 256;
   while (nc < b->len + extra) nc *= 2;
   b->p = (uint8_t *)realloc(b->p, nc);
-  memset(b->p + b->cap, 0, nc - b->cap);
   b->cap = nc;
 }
 static inline void by_push(bytes_t *b, const void *src, size_t n) {
@@ -89,7 +88,7 @@ typedef struct { int code; int64_t detail; } err_t;
 
 static orc_node g_string_node = { K_STRING, 0, 0, 0, 0, 0, 0 };
 
-static builder *mk_builder(const schema_t *s, int idx) {
+static builder *mk_builder(const schema_t *s, int idx, size_t cap) {
   builder *b = (builder *)calloc(1, sizeof(builder));
   b->node = idx < 0 ? &g_string_node : &s->nodes[idx];
   int k = b->node->kind;
@@ -97,11 +96,17 @@ static builder *mk_builder(const schema_t *s, int idx) {
     int32_t z = 0; by_push(&b->offsets, &z, 4);
   }
   if (k == K_RECORD || k == K_LIST || k == K_MAP) b->nulls.materialized = 1; /* plain BooleanBufferBuilder */
+  /* capacity hints, as with_capacity(cap) / (cap, cap*16) in fast_decode.rs:178-194,226,257-260 */
+  if (k == K_STRING || k == K_ENUM) { by_reserve(&b->values, cap * 16); by_reserve(&b->offsets, (cap + 1) * 4); }
+  else if (k == K_LIST || k == K_MAP) by_reserve(&b->offsets, (cap + 1) * 4);
+  else if (k == K_INT || k == K_DATE || k == K_FLOAT) by_reserve(&b->values, cap * 4);
+  else if (k == K_LONG || k == K_TSMILLI || k == K_TSMICRO || k == K_DOUBLE) by_reserve(&b->values, cap * 8);
+  else if (k == K_UNION) by_reserve(&b->type_ids, cap);
   if (b->node->nchildren) {
     b->kids = (builder **)calloc(b->node->nchildren, sizeof(builder *));
-    for (int i = 0; i < b->node->nchildren; i++) b->kids[i] = mk_builder(s, s->child_idx[b->node->first_child + i]);
+    for (int i = 0; i < b->node->nchildren; i++) b->kids[i] = mk_builder(s, s->child_idx[b->node->first_child + i], cap);
   }
-  if (k == K_MAP) b->keys = mk_builder(s, -1);
+  if (k == K_MAP) b->keys = mk_builder(s, -1, cap);
   return b;
 }
 static void free_builder(builder *b) {
@@ -336,9 +341,9 @@ void *orc_decode(const orc_node *nodes, int nnodes, const int32_t *child_idx,
   }
   uint64_t sz = n / k;                                  /* build_slices, deserialize.rs:57-68 */
   for (uint64_t i = 0; i < k; i++) {
-    r->tops[i] = mk_builder(&r->s, 0);
     tasks[i].s = &r->s; tasks[i].data = src; tasks[i].offsets = offsets;
     tasks[i].lo = i * sz; tasks[i].hi = (i == k - 1) ? n : (i + 1) * sz;
+    r->tops[i] = mk_builder(&r->s, 0, (size_t)(tasks[i].hi - tasks[i].lo));
     tasks[i].top = r->tops[i];
   }
   if (threaded && k > 1) {

@@ -1,0 +1,140 @@
+"""pyruhvro_amd -- MI355X-native Avro -> Arrow direct decode behind pyruhvro's Python surface.
+
+Same function names, positional signatures, return types and error behaviour
+as the reference's PyO3 module (``/src/lib.rs:56-158`` of Tyler-Sch/pyruhvro):
+
+    deserialize_array(list, schema) -> pyarrow.RecordBatch
+    deserialize_array_threaded(list, schema, num_chunks) -> list[pyarrow.RecordBatch]
+    deserialize_array_threaded_spawn(list, schema, num_chunks) -> list[pyarrow.RecordBatch]
+    serialize_record_batch / serialize_record_batch_spawn  (other direction: not on this path yet)
+
+The decode runs in hand-written HIP kernels on the GPU through the C ABI in
+``include/ruhvro_hip.h`` (``libruhvro_hip.so``).  There is no CPU decode path in
+this package: without the native library or without a HIP device the calls
+raise ``RuntimeError``.
+
+If the process also uses PyTorch-ROCm, import torch BEFORE this package so both
+share torch's bundled HIP runtime (same SONAME, first one loaded wins).
+"""
+from __future__ import annotations
+
+import os
+import threading
+from typing import List
+
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+try:
+    from . import _pyruhvro as _native  # noqa: F401
+except ImportError as _e:  # pragma: no cover - exercised only on an unbuilt tree
+    _native = None
+    _native_error = _e
+
+
+def _require_native():
+    if _native is None:
+        raise RuntimeError(
+            "pyruhvro_amd: native extension not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `python pyruhvro_amd/_build.py`): {_native_error}")
+    return _native
+
+
+# Schema cache keyed by the exact schema string, unbounded -- src/lib.rs:35-54.
+_cache_lock = threading.Lock()
+_cache: dict = {}
+
+
+class _Compiled:
+    __slots__ = ("capsule", "arrow_schema")
+
+    def __init__(self, capsule, arrow_schema):
+        self.capsule = capsule
+        self.arrow_schema = arrow_schema
+
+
+def _get_schema(schema: str) -> _Compiled:
+    if not isinstance(schema, str):
+        raise TypeError("argument 'schema': expected str")
+    with _cache_lock:
+        hit = _cache.get(schema)
+    if hit is not None:
+        return hit
+    nat = _require_native()
+    cap = nat.compile_schema(schema)          # ValueError on a bad / unsupported schema (src/lib.rs:52)
+    addr = nat.export_schema(cap)
+    try:
+        st = pa.DataType._import_from_c(addr)  # "+s" struct whose fields are the batch columns
+    finally:
+        nat.free_struct(addr)
+    comp = _Compiled(cap, pa.schema(list(st)))
+    with _cache_lock:
+        return _cache.setdefault(schema, comp)
+
+
+def arrow_schema(schema: str) -> pa.Schema:
+    """Arrow schema the decode produces for this Avro schema (schema_translate.rs:19-37)."""
+    return _get_schema(schema).arrow_schema
+
+
+def _decode(list_, schema: str, num_chunks: int, want_stats: bool = False, device: int = -1, stream: int = 0):
+    comp = _get_schema(schema)
+    nat = _require_native()
+    if not isinstance(num_chunks, int) or isinstance(num_chunks, bool):
+        raise TypeError("argument 'num_chunks': expected int")
+    if num_chunks < 0:
+        raise OverflowError("can't convert negative int to unsigned")  # usize extraction in PyO3
+    addrs, stats = nat.decode(comp.capsule, list_, num_chunks, device, stream, want_stats)
+    out: List[pa.RecordBatch] = []
+    try:
+        for i, a in enumerate(addrs):
+            out.append(pa.RecordBatch._import_from_c(a, comp.arrow_schema))
+            nat.free_struct(a)     # content was moved into pyarrow, only the shell is left
+            addrs[i] = 0
+    finally:
+        for a in addrs:
+            if a:
+                nat.release_array(a)
+    return out, stats
+
+
+def deserialize_array(list, schema):  # noqa: A002 - the reference's parameter name
+    """src/lib.rs:56-71 -> ruhvro::deserialize::per_datum_deserialize (deserialize.rs:25-30)."""
+    return _decode(list, schema, 1)[0][0]
+
+
+def deserialize_array_threaded(list, schema, num_chunks):  # noqa: A002
+    """src/lib.rs:73-89 -> per_datum_deserialize_threaded (deserialize.rs:76-121):
+    ``clamp(num_chunks, 1, max(len(list), 1))`` batches, chunk order preserved."""
+    return _decode(list, schema, num_chunks)[0]
+
+
+def deserialize_array_threaded_spawn(list, schema, num_chunks):  # noqa: A002
+    """src/lib.rs:108-128 -- same results as deserialize_array_threaded (deserialize.rs:127-170)."""
+    return _decode(list, schema, num_chunks)[0]
+
+
+def deserialize_array_threaded_with_stats(list, schema, num_chunks, device: int = -1):  # noqa: A002
+    """Extension: also returns the engine's per-stage timings (rh_stats)."""
+    return _decode(list, schema, num_chunks, want_stats=True, device=device)
+
+
+def serialize_record_batch(data, schema, num_chunks):
+    """src/lib.rs:91-106 (Arrow -> Avro).  Other direction; not part of the GPU decode path yet."""
+    raise NotImplementedError("serialize_record_batch is outside the Avro->Arrow direct-decode path (SURVEY 8f N1)")
+
+
+def serialize_record_batch_spawn(data, schema, num_chunks):
+    """src/lib.rs:130-148."""
+    raise NotImplementedError("serialize_record_batch_spawn is outside the Avro->Arrow direct-decode path (SURVEY 8f N1)")
+
+
+def device_count() -> int:
+    return _require_native().device_count()
+
+
+__all__ = [
+    "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
+    "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count",
+]

@@ -1,0 +1,770 @@
+// C ABI of the direct-decode engine (include/ruhvro_hip.h): schema cache objects,
+// device memory pools, the k_size -> k_scan -> k_emit launch sequence, and the
+// Arrow C Data / C Device Data export of the produced buffers.
+//
+// Replaces, for the one hot path, the reference's chunk driver
+// (ruhvro/src/deserialize.rs:76-121: pack, slice, one task per chunk, ordered
+// join) -- the device boundary takes the place of the spawn_blocking boundary.
+// There is NO CPU decode fallback in this library: without a HIP device every
+// decode entry point fails with RH_ERR_RUNTIME.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ruhvro_hip.h"
+#include "program.h"
+#include "schema.h"
+
+extern "C" {
+int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream);
+int rh_launch_scan(const rh::KParams* P, void* stream);
+int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
+                   void* stream);
+int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream);
+int rh_set_max_lds(uint32_t bytes);
+uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes);
+}
+
+namespace {
+
+using rh::CompiledSchema;
+using rh::DecNode;
+
+struct HipError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+struct DecodeError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw HipError(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);      \
+  } while (0)
+
+char* dup_msg(const std::string& s) {
+  char* p = (char*)std::malloc(s.size() + 1);
+  if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+constexpr uint64_t kAlign = 256;
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------
+// caching device / pinned-host pools (one per process; blocks are reused across calls so a
+// steady-state decode does no hipMalloc)
+// ---------------------------------------------------------------------------
+struct Block {
+  void* p = nullptr;
+  uint64_t size = 0;
+  int device = 0;
+};
+
+class Pool {
+ public:
+  explicit Pool(bool host) : host_(host) {}
+  Block get(uint64_t size, int device) {
+    size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      int best = -1;
+      for (size_t i = 0; i < free_.size(); i++) {
+        if ((host_ || free_[i].device == device) && free_[i].size >= size && free_[i].size <= size * 2 + (1 << 20)) {
+          if (best < 0 || free_[i].size < free_[best].size) best = (int)i;
+        }
+      }
+      if (best >= 0) {
+        Block b = free_[best];
+        free_.erase(free_.begin() + best);
+        cached_ -= b.size;
+        return b;
+      }
+    }
+    Block b;
+    b.size = size;
+    b.device = device;
+    hipError_t e = host_ ? hipHostMalloc(&b.p, size, hipHostMallocDefault) : hipMalloc(&b.p, size);
+    if (e != hipSuccess) {
+      trim(0);
+      e = host_ ? hipHostMalloc(&b.p, size, hipHostMallocDefault) : hipMalloc(&b.p, size);
+    }
+    if (e != hipSuccess) throw HipError(std::string("HIP allocation of ") + std::to_string(size) + " bytes failed: " + hipGetErrorString(e));
+    return b;
+  }
+  void put(Block b) {
+    if (!b.p) return;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      free_.push_back(b);
+      cached_ += b.size;
+    }
+    trim(kMaxCached);
+  }
+  void trim(uint64_t keep) {
+    std::vector<Block> drop;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      while (cached_ > keep && !free_.empty()) {
+        size_t big = 0;
+        for (size_t i = 1; i < free_.size(); i++)
+          if (free_[i].size > free_[big].size) big = i;
+        drop.push_back(free_[big]);
+        cached_ -= free_[big].size;
+        free_.erase(free_.begin() + big);
+      }
+    }
+    for (auto& b : drop) {
+      if (host_) (void)hipHostFree(b.p);
+      else (void)hipFree(b.p);
+    }
+  }
+
+ private:
+  static constexpr uint64_t kMaxCached = 24ull << 30;
+  bool host_;
+  std::mutex mu_;
+  std::vector<Block> free_;
+  uint64_t cached_ = 0;
+};
+
+Pool& dev_pool() { static Pool* p = new Pool(false); return *p; }
+Pool& pin_pool() { static Pool* p = new Pool(true); return *p; }
+
+struct Lease {   // RAII pool block
+  Pool* pool = nullptr;
+  Block b;
+  Lease() = default;
+  Lease(Pool& p, uint64_t size, int device) : pool(&p), b(p.get(size, device)) {}
+  Lease(const Lease&) = delete;
+  Lease& operator=(const Lease&) = delete;
+  Lease(Lease&& o) noexcept : pool(o.pool), b(o.b) { o.pool = nullptr; o.b = Block(); }
+  Lease& operator=(Lease&& o) noexcept {
+    if (this != &o) { release(); pool = o.pool; b = o.b; o.pool = nullptr; o.b = Block(); }
+    return *this;
+  }
+  ~Lease() { release(); }
+  void release() { if (pool && b.p) pool->put(b); pool = nullptr; b = Block(); }
+  uint8_t* ptr() const { return (uint8_t*)b.p; }
+};
+
+// ---------------------------------------------------------------------------
+// compiled schema + its per-device copy
+// ---------------------------------------------------------------------------
+struct DeviceProgram {
+  rh::Op* prog = nullptr;
+  uint32_t* sym_off = nullptr;
+  uint8_t* sym_data = nullptr;
+  rh::BufDesc* desc = nullptr;
+};
+
+}  // namespace
+
+struct rh_schema {
+  std::unique_ptr<CompiledSchema> cs;
+  std::mutex mu;
+  std::map<int, DeviceProgram> dev;
+};
+
+namespace {
+
+const DeviceProgram& device_program(rh_schema* s, int device) {
+  std::lock_guard<std::mutex> g(s->mu);
+  auto it = s->dev.find(device);
+  if (it != s->dev.end()) return it->second;
+  const CompiledSchema& cs = *s->cs;
+  DeviceProgram d;
+  const size_t pb = cs.prog.size() * sizeof(rh::Op), so = cs.sym_off.size() * 4, sd = cs.sym_data.size(),
+               bd = std::max<size_t>(cs.bufs.size(), 1) * sizeof(rh::BufDesc);
+  HIPCHK(hipMalloc((void**)&d.prog, pb));
+  HIPCHK(hipMalloc((void**)&d.sym_off, so));
+  HIPCHK(hipMalloc((void**)&d.sym_data, sd));
+  HIPCHK(hipMalloc((void**)&d.desc, bd));
+  HIPCHK(hipMemcpy(d.prog, cs.prog.data(), pb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.sym_off, cs.sym_off.data(), so, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.sym_data, cs.sym_data.data(), sd, hipMemcpyHostToDevice));
+  if (!cs.bufs.empty()) HIPCHK(hipMemcpy(d.desc, cs.bufs.data(), cs.bufs.size() * sizeof(rh::BufDesc), hipMemcpyHostToDevice));
+  return s->dev.emplace(device, d).first->second;
+}
+
+std::string format_error(const rh::ErrInfo& e) {
+  char buf[128];
+  switch (e.code) {
+    case rh::E_EOB: return "unexpected end of buffer";
+    case rh::E_VARINT: return "zigzag varint too long";
+    case rh::E_EOB_F32: return "unexpected end of buffer (f32)";
+    case rh::E_EOB_F64: return "unexpected end of buffer (f64)";
+    case rh::E_BOOL: std::snprintf(buf, sizeof buf, "invalid boolean byte: %lld", (long long)e.detail); return buf;
+    case rh::E_NEGLEN: return "negative string length";
+    case rh::E_EOB_STR: return "unexpected end of buffer (string)";
+    case rh::E_ENUM: std::snprintf(buf, sizeof buf, "enum index %llu out of range", (unsigned long long)e.detail); return buf;
+    case rh::E_BRANCH: std::snprintf(buf, sizeof buf, "invalid union branch index: %lld", (long long)e.detail); return buf;
+    case rh::E_UNION: std::snprintf(buf, sizeof buf, "union branch index out of range: %lld", (long long)e.detail); return buf;
+    case rh::E_LIST_RANGE:
+      std::snprintf(buf, sizeof buf, "array/map block count %lld of zero-width items exceeds the supported range", (long long)e.detail);
+      return buf;
+    default: return "decode error";
+  }
+}
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  float ms() const { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// device result
+// ---------------------------------------------------------------------------
+struct rh_device_result {
+  const CompiledSchema* cs = nullptr;
+  int device = 0;
+  uint64_t n = 0, sz = 0, rows_last = 0;
+  uint32_t k = 1;
+  Lease arena;                         // all Arrow buffers of all chunks
+  uint64_t arena_bytes = 0;
+  std::vector<uint64_t> buf_off;       // [nbuf][k] offset into arena
+  std::vector<uint64_t> buf_size;      // [nbuf][k] allocated bytes
+  std::vector<uint64_t> dom_rows;      // [ndom][k]
+  std::vector<uint64_t> data_bytes;    // [K][k] totals
+  std::vector<uint32_t> nullcount;     // [nnodes][k]
+  uint64_t output_bytes = 0;           // exact (unpadded) Arrow bytes
+
+  uint64_t rows(int dom, uint32_t c) const { return dom_rows[(size_t)dom * k + c]; }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Arrow C Data export
+// ---------------------------------------------------------------------------
+struct Slab {   // host copy of the arena, shared by the k chunk arrays
+  std::atomic<int> refs{0};
+  void* base = nullptr;
+};
+
+struct ArrayPriv {
+  std::vector<const void*> buffers;
+  std::vector<ArrowArray*> children;
+  Slab* slab = nullptr;   // top-level arrays only
+};
+
+void release_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  ArrayPriv* p = (ArrayPriv*)a->private_data;
+  for (ArrowArray* c : p->children) {
+    if (c->release) c->release(c);
+    delete c;
+  }
+  if (p->slab && p->slab->refs.fetch_sub(1) == 1) {
+    std::free(p->slab->base);
+    delete p->slab;
+  }
+  delete p;
+  a->release = nullptr;
+}
+
+void init_array(ArrowArray* a, int64_t length, int64_t null_count, std::vector<const void*> bufs,
+                std::vector<ArrowArray*> kids) {
+  ArrayPriv* p = new ArrayPriv();
+  p->buffers = std::move(bufs);
+  p->children = std::move(kids);
+  a->length = length;
+  a->null_count = null_count;
+  a->offset = 0;
+  a->n_buffers = (int64_t)p->buffers.size();
+  a->n_children = (int64_t)p->children.size();
+  a->buffers = p->buffers.empty() ? nullptr : p->buffers.data();
+  a->children = p->children.empty() ? nullptr : p->children.data();
+  a->dictionary = nullptr;
+  a->release = release_array;
+  a->private_data = p;
+}
+
+// Builds the array of decoder node `id` for chunk c; `base` is the arena base (host slab or device).
+ArrowArray* export_node(const rh_device_result& r, int id, uint32_t c, const uint8_t* base) {
+  const CompiledSchema& cs = *r.cs;
+  const DecNode& n = cs.nodes[id];
+  const int64_t len = (int64_t)r.rows(n.dom, c);
+  const int64_t nulls = (int64_t)r.nullcount[(size_t)id * r.k + c];
+  auto bp = [&](int buf) -> const void* { return buf < 0 ? nullptr : base + r.buf_off[(size_t)buf * r.k + c]; };
+  ArrowArray* a = new ArrowArray();
+  switch (n.kind) {
+    case rh::NK_FIXED:
+      // leaf builders keep a lazy null buffer: bitmap only if a null was appended
+      init_array(a, len, nulls, {nulls > 0 ? bp(n.buf_validity) : nullptr, bp(n.buf_main)}, {});
+      break;
+    case rh::NK_STRING: case rh::NK_ENUM:
+      init_array(a, len, nulls, {nulls > 0 ? bp(n.buf_validity) : nullptr, bp(n.buf_main), bp(n.buf_data)}, {});
+      break;
+    case rh::NK_NULL:
+      init_array(a, len, len, {}, {});
+      break;
+    case rh::NK_RECORD: {   // fast_decode.rs:618-639: validity iff the record decoder is nullable
+      std::vector<ArrowArray*> kids;
+      for (int ch : n.children) kids.push_back(export_node(r, ch, c, base));
+      init_array(a, len, n.nullable ? nulls : 0, {n.nullable ? bp(n.buf_validity) : nullptr}, std::move(kids));
+      break;
+    }
+    case rh::NK_UNION: {    // fast_decode.rs:670-683: sparse, type_ids only
+      std::vector<ArrowArray*> kids;
+      for (int ch : n.children) kids.push_back(export_node(r, ch, c, base));
+      init_array(a, len, 0, {bp(n.buf_main)}, std::move(kids));
+      break;
+    }
+    case rh::NK_LIST: {     // fast_decode.rs:729-741
+      ArrowArray* item = export_node(r, n.children[0], c, base);
+      init_array(a, len, n.nullable ? nulls : 0, {n.nullable ? bp(n.buf_validity) : nullptr, bp(n.buf_main)}, {item});
+      break;
+    }
+    case rh::NK_MAP: {      // fast_decode.rs:772-798
+      ArrowArray* keys = export_node(r, n.keys, c, base);
+      ArrowArray* vals = export_node(r, n.children[0], c, base);
+      ArrowArray* entries = new ArrowArray();
+      init_array(entries, (int64_t)r.rows(n.child_dom, c), 0, {nullptr}, {keys, vals});
+      init_array(a, len, n.nullable ? nulls : 0, {n.nullable ? bp(n.buf_validity) : nullptr, bp(n.buf_main)}, {entries});
+      break;
+    }
+  }
+  return a;
+}
+
+void export_chunk(const rh_device_result& r, uint32_t c, const uint8_t* base, Slab* slab, ArrowArray* out) {
+  const DecNode& top = r.cs->nodes[0];
+  std::vector<ArrowArray*> kids;
+  for (int ch : top.children) kids.push_back(export_node(r, ch, c, base));
+  init_array(out, (int64_t)r.rows(0, c), 0, {nullptr}, std::move(kids));
+  if (slab) {
+    ((ArrayPriv*)out->private_data)->slab = slab;
+    slab->refs.fetch_add(1);
+  }
+}
+
+// ---- ArrowSchema export -----------------------------------------------------
+struct SchemaPriv {
+  std::string format, name, metadata;
+  std::vector<ArrowSchema*> children;
+};
+
+void release_schema(ArrowSchema* s) {
+  if (!s || !s->release) return;
+  SchemaPriv* p = (SchemaPriv*)s->private_data;
+  for (ArrowSchema* c : p->children) {
+    if (c->release) c->release(c);
+    delete c;
+  }
+  delete p;
+  s->release = nullptr;
+}
+
+void export_field(const rh::ArrowField& f, ArrowSchema* out) {
+  SchemaPriv* p = new SchemaPriv();
+  p->format = f.format;
+  p->name = f.name;
+  if (!f.metadata.empty()) {   // int32 count, then (int32 len, bytes) x2 per pair, native endianness
+    auto put32 = [&](int32_t v) { p->metadata.append((const char*)&v, 4); };
+    put32((int32_t)f.metadata.size());
+    for (auto& kv : f.metadata) {
+      put32((int32_t)kv.first.size()); p->metadata += kv.first;
+      put32((int32_t)kv.second.size()); p->metadata += kv.second;
+    }
+  }
+  for (auto& ch : f.children) {
+    ArrowSchema* cs = new ArrowSchema();
+    export_field(ch, cs);
+    p->children.push_back(cs);
+  }
+  out->format = p->format.c_str();
+  out->name = p->name.c_str();
+  out->metadata = p->metadata.empty() ? nullptr : p->metadata.data();
+  out->flags = (f.nullable ? ARROW_FLAG_NULLABLE : 0) | (f.map_keys_sorted ? ARROW_FLAG_MAP_KEYS_SORTED : 0);
+  out->n_children = (int64_t)p->children.size();
+  out->children = p->children.empty() ? nullptr : p->children.data();
+  out->dictionary = nullptr;
+  out->release = release_schema;
+  out->private_data = p;
+}
+
+// ---------------------------------------------------------------------------
+// the launch sequence
+// ---------------------------------------------------------------------------
+struct Events {
+  hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool on = false;
+  void init() { for (auto& x : e) HIPCHK(hipEventCreate(&x)); on = true; }
+  ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+  void rec(int i, hipStream_t s) { if (on) HIPCHK(hipEventRecord(e[i], s)); }
+  float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
+};
+
+rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
+                                     uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats) {
+  const CompiledSchema& cs = *s->cs;
+  int device = 0;
+  if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
+  else HIPCHK(hipGetDevice(&device));
+  hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+  if ((uintptr_t)d_data & 15) throw std::invalid_argument("device payload pointer must be 16-byte aligned");
+
+  static std::once_flag lds_once;
+  std::call_once(lds_once, [] { (void)rh_set_max_lds(160 * 1024); });
+
+  auto res = std::make_unique<rh_device_result>();
+  rh_device_result& r = *res;
+  r.cs = &cs;
+  r.device = device;
+  r.n = n;
+  const uint32_t k = rh_clamp_chunks(n, num_chunks);
+  r.k = k;
+  r.sz = n / k;
+  r.rows_last = n - (uint64_t)(k - 1) * r.sz;
+  const int K = cs.K, nnodes = (int)cs.nodes.size(), nbuf = (int)cs.bufs.size();
+  const uint64_t bpc64 = std::max<uint64_t>((r.sz + rh::kBlock - 1) / rh::kBlock, 1);
+  const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + rh::kBlock - 1) / rh::kBlock;
+  if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
+  const uint32_t nblocks = (uint32_t)nblocks64;
+
+  const DeviceProgram& dp = device_program(s, device);
+
+  // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
+  const uint64_t o_null = 16;
+  const uint64_t o_tot = align_up(o_null + 4ull * nnodes * k, 8);
+  const uint64_t ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
+  const uint64_t o_err = ctrl_bytes;
+  const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
+  const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
+  const uint64_t ws_bytes = align_up(o_bbase + 4ull * K * nblocks, kAlign);
+  Lease ws(dev_pool(), ws_bytes, device);
+  Lease hctrl(pin_pool(), ctrl_bytes, device);
+  HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
+
+  rh::KParams P;
+  std::memset(&P, 0, sizeof P);
+  P.data = d_data; P.offsets = d_offsets; P.data_len = data_len;
+  P.n = n; P.sz = r.sz; P.rows_last = r.rows_last; P.k = k; P.bpc = (uint32_t)bpc64; P.nblocks = nblocks;
+  P.prog = dp.prog; P.sym_off = dp.sym_off; P.sym_data = dp.sym_data;
+  P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
+  P.first_bad = (unsigned long long*)ws.ptr();
+  P.nullcount = (uint32_t*)(ws.ptr() + o_null);
+  P.totals = (uint64_t*)(ws.ptr() + o_tot);
+  P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
+  P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
+  P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
+
+  // LDS: fixed part + input window sized from the mean record length (falls back to global reads
+  // for workgroups whose 256 records do not fit)
+  const uint32_t lds_fixed = rh_lds_fixed_bytes(K, cs.list_depth, nnodes);
+  const uint64_t avg = n ? data_len / n + 1 : 16;
+  uint64_t win = align_up(avg * rh::kBlock * 115 / 100 + 2048, 16);
+  win = std::max<uint64_t>(win, 8192);
+  const uint64_t lds_cap = 160 * 1024 - 512;
+  if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
+  win = std::min<uint64_t>(win, std::min<uint64_t>(lds_cap - lds_fixed, 96 * 1024));
+  P.win_bytes = (uint32_t)win;
+  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;
+
+  Events ev;
+  if (stats) ev.init();
+  auto check_bad = [&](const uint8_t* h) {
+    unsigned long long fb = *(const unsigned long long*)h;
+    if (!fb) return;
+    const uint64_t rec = ~fb;
+    uint64_t c = r.sz ? std::min<uint64_t>(rec / r.sz, k - 1) : 0;
+    uint64_t b = c * bpc64 + (rec - c * r.sz) / rh::kBlock;
+    rh::ErrInfo ei;
+    HIPCHK(hipMemcpy(&ei, P.errinfo + b, sizeof ei, hipMemcpyDeviceToHost));
+    throw DecodeError(format_error(ei));
+  };
+
+  ev.rec(0, stream);
+  std::vector<uint64_t> totals((size_t)K * k, 0);
+  if (n > 0 && K > 0) {
+    if (rh_launch_size(&P, lds_bytes, stream)) throw HipError("k_size launch failed");
+    ev.rec(1, stream);
+    if (rh_launch_scan(&P, stream)) throw HipError("k_scan launch failed");
+    ev.rec(2, stream);
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    check_bad(hctrl.ptr());
+    std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
+  } else {
+    ev.rec(1, stream);
+    ev.rec(2, stream);
+  }
+
+  // ---- output arena layout (sizes are exact Arrow sizes, each buffer 256-byte aligned)
+  r.dom_rows.assign((size_t)cs.ndom * k, 0);
+  for (uint32_t c = 0; c < k; c++) {
+    r.dom_rows[c] = n == 0 ? 0 : (c == k - 1 ? r.rows_last : r.sz);
+    for (int d = 1; d < cs.ndom; d++) r.dom_rows[(size_t)d * k + c] = totals[(size_t)(d - 1) * k + c];
+  }
+  r.data_bytes = totals;
+  for (auto t : totals)
+    if (t > 0x7FFFFFFFull) throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
+  r.buf_off.assign((size_t)nbuf * k, 0);
+  r.buf_size.assign((size_t)nbuf * k, 0);
+  uint64_t off = 0, exact = 0;
+  for (uint32_t c = 0; c < k; c++) {
+    for (int b = 0; b < nbuf; b++) {
+      const rh::BufDesc& d = cs.bufs[b];
+      const uint64_t rows = r.rows(d.dom, c);
+      uint64_t sz = 0, ex = 0;
+      switch (d.kind) {
+        case rh::BK_BITMAP: sz = (rows + 63) / 64 * 8; ex = (rows + 7) / 8; break;
+        case rh::BK_VAL4: sz = ex = rows * 4; break;
+        case rh::BK_VAL8: sz = ex = rows * 8; break;
+        case rh::BK_I8: sz = ex = rows; break;
+        case rh::BK_OFFSETS: sz = ex = (rows + 1) * 4; break;
+        case rh::BK_DATA: sz = ex = totals[(size_t)d.counter * k + c]; break;
+      }
+      r.buf_off[(size_t)b * k + c] = off;
+      r.buf_size[(size_t)b * k + c] = sz;
+      off += align_up(std::max<uint64_t>(sz, 8), kAlign);
+      exact += ex;
+    }
+  }
+  r.arena_bytes = std::max<uint64_t>(off, kAlign);
+  r.output_bytes = exact;
+  r.arena = Lease(dev_pool(), r.arena_bytes, device);
+
+  // pointer + size tables -> device
+  const uint64_t tab_bytes = align_up((uint64_t)std::max(nbuf, 1) * k * 16, kAlign);
+  Lease htab(pin_pool(), tab_bytes, device);
+  Lease dtab(dev_pool(), tab_bytes, device);
+  void** hptr = (void**)htab.ptr();
+  uint64_t* hsz = (uint64_t*)(htab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
+  for (size_t i = 0; i < (size_t)nbuf * k; i++) { hptr[i] = r.arena.ptr() + r.buf_off[i]; hsz[i] = r.buf_size[i]; }
+  HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
+  P.bufptr = (void* const*)dtab.ptr();
+  const uint64_t* d_sizes = (const uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
+
+  if (nbuf > 0 && rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, stream)) throw HipError("k_init launch failed");
+  ev.rec(3, stream);
+  if (n > 0) {
+    if (rh_launch_emit(&P, lds_bytes, stream)) throw HipError("k_emit launch failed");
+  }
+  ev.rec(4, stream);
+  HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  check_bad(hctrl.ptr());
+  r.nullcount.assign((size_t)nnodes * k, 0);
+  std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
+
+  if (stats) {
+    stats->records = n;
+    stats->input_bytes = data_len;
+    stats->output_bytes = exact;
+    stats->chunks = k;
+    stats->blocks = nblocks;
+    stats->size_kernel_ms = ev.ms(0, 1);
+    stats->scan_kernel_ms = ev.ms(1, 2);
+    stats->emit_kernel_ms = ev.ms(3, 4);
+  }
+  return res.release();
+}
+
+int to_host_impl(rh_device_result* r, ArrowArray* out_chunks) {
+  Slab* slab = new Slab();
+  if (posix_memalign(&slab->base, 64, r->arena_bytes) != 0) { delete slab; throw std::bad_alloc(); }
+  hipError_t e = hipMemcpy(slab->base, r->arena.ptr(), r->arena_bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { std::free(slab->base); delete slab; throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e)); }
+  slab->refs.store(1);   // guard while building
+  for (uint32_t c = 0; c < r->k; c++) export_chunk(*r, c, (const uint8_t*)slab->base, slab, &out_chunks[c]);
+  if (slab->refs.fetch_sub(1) == 1) { std::free(slab->base); delete slab; }
+  return 0;
+}
+
+template <typename F>
+int guarded(char** err, F&& f) {
+  try {
+    return f();
+  } catch (const rh::SchemaError& e) {
+    if (err) *err = dup_msg(e.what());
+    return RH_ERR_SCHEMA;
+  } catch (const DecodeError& e) {
+    if (err) *err = dup_msg(e.what());
+    return RH_ERR_DECODE;
+  } catch (const std::invalid_argument& e) {
+    if (err) *err = dup_msg(e.what());
+    return RH_ERR_ARGUMENT;
+  } catch (const std::exception& e) {
+    if (err) *err = dup_msg(e.what());
+    return RH_ERR_RUNTIME;
+  }
+}
+
+void require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw HipError("no HIP device available: the ruhvro_hip engine has no CPU decode path");
+}
+
+int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
+                       const rh_opts* opts, ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, float pack_ms) {
+  require_device();
+  Timer total;
+  int device = 0;
+  if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
+  else HIPCHK(hipGetDevice(&device));
+  hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+  const uint64_t data_len = offsets[n];
+  const uint64_t o_off = align_up(data_len + 16, kAlign);
+  Lease din(dev_pool(), o_off + 8 * (n + 1), device);
+  Timer th;
+  if (data_len) HIPCHK(hipMemcpyAsync(din.ptr(), data, data_len, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  const float h2d = th.ms();
+  std::unique_ptr<rh_device_result> r(decode_device_impl(s, din.ptr(), (const uint64_t*)(din.ptr() + o_off), data_len,
+                                                         n, num_chunks, opts, stats));
+  Timer td;
+  to_host_impl(r.get(), out_chunks);
+  if (out_k) *out_k = r->k;
+  if (stats) {
+    stats->pack_ms = pack_ms;
+    stats->h2d_ms = h2d;
+    stats->d2h_ms = td.ms();
+    stats->total_ms = total.ms() + pack_ms;
+  }
+  return RH_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int rh_abi_version(void) { return RH_ABI_VERSION; }
+
+int rh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void rh_free_string(char* s) { std::free(s); }
+
+uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks) {   // deserialize.rs:53-55
+  uint64_t k = std::max<uint64_t>(num_chunks, 1);
+  k = std::min<uint64_t>(k, std::max<uint64_t>(n, 1));
+  return (uint32_t)std::min<uint64_t>(k, 0xFFFFFFFFull);
+}
+
+rh_schema* rh_schema_compile(const char* json, size_t len, char** err) {
+  rh_schema* out = nullptr;
+  guarded(err, [&] {
+    auto cs = rh::compile_schema(json, len);
+    out = new rh_schema();
+    out->cs = std::move(cs);
+    return RH_OK;
+  });
+  return out;
+}
+
+void rh_schema_free(rh_schema* s) {
+  if (!s) return;
+  for (auto& kv : s->dev) {
+    (void)hipFree(kv.second.prog);
+    (void)hipFree(kv.second.sym_off);
+    (void)hipFree(kv.second.sym_data);
+    (void)hipFree(kv.second.desc);
+  }
+  delete s;
+}
+
+int rh_schema_export(const rh_schema* s, struct ArrowSchema* out) {
+  if (!s || !out) return RH_ERR_ARGUMENT;
+  export_field(s->cs->arrow, out);
+  return RH_OK;
+}
+
+int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offsets, uint64_t data_len, uint64_t n,
+                     uint64_t num_chunks, const rh_opts* opts, rh_device_result** out, rh_stats* stats, char** err) {
+  if (!s || !out) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] {
+    require_device();
+    Timer t;
+    *out = decode_device_impl(const_cast<rh_schema*>(s), (const uint8_t*)d_data, (const uint64_t*)d_offsets, data_len,
+                              n, num_chunks, opts, stats);
+    if (stats) stats->total_ms = t.ms();
+    return RH_OK;
+  });
+}
+
+uint32_t rh_device_result_chunks(const rh_device_result* r) { return r ? r->k : 0; }
+
+uint64_t rh_device_result_output_bytes(const rh_device_result* r) { return r ? r->output_bytes : 0; }
+
+int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDeviceArray* out) {
+  if (!r || !out || chunk >= r->k) return RH_ERR_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  export_chunk(*r, chunk, r->arena.ptr(), nullptr, &out->array);
+  out->device_id = r->device;
+  out->device_type = ARROW_DEVICE_ROCM;
+  out->sync_event = nullptr;   // the producing stream was synchronised before the result was returned
+  return RH_OK;
+}
+
+int rh_device_result_to_host(rh_device_result* r, struct ArrowArray* out_chunks, char** err) {
+  if (!r || !out_chunks) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] { return to_host_impl(r, out_chunks); });
+}
+
+void rh_device_result_free(rh_device_result* r) { delete r; }
+
+int rh_decode_packed(const rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
+                     const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
+  if (!s || !offsets || !out_chunks) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] {
+    return decode_packed_impl(const_cast<rh_schema*>(s), data, offsets, n, num_chunks, opts, out_chunks, out_k, stats, 0.f);
+  });
+}
+
+int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint64_t num_chunks,
+              const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
+  if (!s || !out_chunks || (n && (!ptrs || !lens))) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] {
+    require_device();
+    // gather the record slices into one pinned buffer (the reference's BinaryArray::from_vec,
+    // deserialize.rs:90, but parallel and straight into DMA-able memory)
+    Timer tp;
+    std::vector<uint64_t> offsets(n + 1);
+    uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) { offsets[i] = tot; tot += lens[i]; }
+    offsets[n] = tot;
+    Lease pin(pin_pool(), tot + 16, 0);
+    uint8_t* dst = pin.ptr();
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (tot < (4u << 20)) nt = 1;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+      for (uint64_t i = lo; i < hi; i++) std::memcpy(dst + offsets[i], ptrs[i], lens[i]);
+    };
+    if (nt == 1) work(0, n);
+    else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+      for (auto& x : th) x.join();
+    }
+    const float pack_ms = tp.ms();
+    return decode_packed_impl(const_cast<rh_schema*>(s), dst, offsets.data(), n, num_chunks, opts, out_chunks, out_k,
+                              stats, pack_ms);
+  });
+}
+
+}  // extern "C"

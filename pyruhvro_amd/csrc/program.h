@@ -1,0 +1,107 @@
+// Schema program: the flat, wave-uniform form of the reference's decoder tree
+// (FieldDecoder / RecordDecoder / UnionDecoder / ListDecoder / MapDecoder,
+// ruhvro/src/fast_decode.rs:73-167).  Built on the host by schema.cpp, run by
+// the interpreter in kernels.hip.  Shared between host and device code.
+#pragma once
+#include <stdint.h>
+
+namespace rh {
+
+constexpr int kBlock = 256;          // threads (= records) per workgroup
+constexpr int kMaxCounters = 96;     // scanned per-record counters (row domains + string columns)
+constexpr int kMaxListDepth = 8;     // nested array/map levels
+constexpr int kMaxNest = 30;         // nested nullable-record / union / list levels (bit stacks)
+constexpr int kMaxUnionDepth = 8;    // nested N-variant unions (8-bit selector stack in a u64)
+
+enum FixedKind : int32_t { FK_I32 = 0, FK_I64 = 1, FK_F32 = 2, FK_F64 = 3, FK_BOOL = 4 };
+
+enum OpCode : int32_t {
+  OP_END = 0,
+  OP_FIXED,        // int/long/float/double/boolean/date/timestamp leaf       (fast_decode.rs:424-432,434-473)
+  OP_STRING,       // string leaf, also map keys                              (429,454-457,752)
+  OP_ENUM,         // enum -> symbol text                                     (433,474-479,570-578)
+  OP_REC_BEGIN,    // nullable record: branch + validity, children follow     (482-485,595-616)
+  OP_REC_END,
+  OP_UNION_BEGIN,  // N-variant union: branch -> type_id                      (643-668)
+  OP_VARIANT,      // start of variant i's ops
+  OP_UNION_END,
+  OP_LIST_BEGIN,   // array / map (optionally nullable)                       (487-496,703-727,745-770)
+  OP_LIST_NEXT,    // block header / loop head                                (689-700)
+  OP_LIST_TAIL,    // end of one item
+  OP_LIST_END,     // push offset
+};
+
+enum OpFlags : int32_t {
+  F_NULLABLE = 1,    // 2-variant null union collapsed onto this node (Nullable* decoders)
+  F_NULL_FIRST = 2,  // union was ["null", T]
+  F_CAN_NULL = 4,    // node can receive append_null -> it owns a validity bitmap
+  F_IS_MAP = 8,
+};
+
+struct Op {
+  int32_t code;
+  int32_t flags;
+  int32_t dom;    // row domain the node's rows live in (0 = records)
+  int32_t a;      // FIXED: FixedKind | STRING/ENUM: counter id of the byte column | UNION_BEGIN: #variants
+                  // VARIANT: variant index | LIST_*: child row domain
+  int32_t b;      // ENUM: first index into sym_off | LIST_BEGIN/NEXT: pc of LIST_END | LIST_TAIL: pc of LIST_NEXT
+  int32_t c;      // ENUM: #symbols | LIST_*: list nesting depth
+  int32_t buf0;   // validity bitmap buffer id, or -1
+  int32_t buf1;   // values / offsets / type_ids buffer id, or -1
+  int32_t buf2;   // string data buffer id, or -1 | LIST_NEXT: min wire bytes per item (0 = zero-width items)
+  int32_t node;   // node id (null-count slot)
+};
+
+// decode error codes (message text: fast_decode.rs:575,591,646,849,866,874,884,898,906,910)
+enum ErrCode : uint32_t {
+  E_OK = 0, E_EOB, E_VARINT, E_EOB_F32, E_EOB_F64, E_BOOL, E_NEGLEN, E_EOB_STR, E_ENUM, E_BRANCH, E_UNION,
+  E_LIST_RANGE,   // zero-width items with a block count beyond the i32 offset range (no reference message)
+};
+
+struct ErrInfo {
+  uint32_t code;
+  uint32_t pad;
+  int64_t detail;
+};
+
+enum BufKind : int32_t { BK_BITMAP = 0, BK_VAL4, BK_VAL8, BK_I8, BK_OFFSETS, BK_DATA };
+
+struct BufDesc {
+  int32_t kind;
+  int32_t dom;      // row domain
+  int32_t counter;  // BK_DATA: counter id giving its byte length
+  int32_t node;
+};
+
+// Kernel parameters (one launch = all chunks of one call on one device).
+struct KParams {
+  const uint8_t* data;       // packed Avro payload
+  const uint64_t* offsets;   // n+1 record offsets into data
+  uint64_t data_len;
+  uint64_t n;                // records
+  uint64_t sz;               // rows per chunk except the last (deserialize.rs:58)
+  uint64_t rows_last;        // rows of the last chunk
+  uint32_t k;                // chunks
+  uint32_t bpc;              // workgroups per (non-last) chunk
+  uint32_t nblocks;
+  uint32_t win_bytes;        // LDS bytes reserved for the input window
+
+  const Op* prog;
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  int32_t nops;
+  int32_t K;                 // counters
+  int32_t ndom;              // row domains (>= 1)
+  int32_t nnodes;
+  int32_t list_depth;        // max list nesting (LDS rem[] rows)
+
+  uint32_t* blocksum;        // [K][nblocks]
+  uint32_t* blockbase;       // [K][nblocks] chunk-relative exclusive prefix
+  uint64_t* totals;          // [K][k]
+  unsigned long long* first_bad;  // lowest failing record index, ~0 if none
+  ErrInfo* errinfo;          // [nblocks]
+  void* const* bufptr;       // [nbuf][k]
+  uint32_t* nullcount;       // [nnodes][k]
+};
+
+}  // namespace rh

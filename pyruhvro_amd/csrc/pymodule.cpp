@@ -1,0 +1,197 @@
+// CPython extension `_pyruhvro`: the GIL-side half of the Python boundary.
+//
+// Mirrors what the reference's PyO3 layer does around the native call
+// (src/lib.rs:29-33 extract_bytes_list, 64-68/82-86 py.detach, 25-27 error
+// mapping): borrow (ptr, len) of every `bytes` in the list while holding the
+// GIL and a strong reference, release the GIL, call the C ABI
+// (include/ruhvro_hip.h), and hand the resulting Arrow C structs to Python as
+// raw addresses that pyarrow imports (`RecordBatch._import_from_c`).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ruhvro_hip.h"
+
+namespace {
+
+const char* kCapsule = "ruhvro_hip.schema";
+
+void capsule_free(PyObject* cap) {
+  rh_schema* s = (rh_schema*)PyCapsule_GetPointer(cap, kCapsule);
+  if (s) rh_schema_free(s);
+}
+
+PyObject* raise_from(int rc, char* err) {
+  std::string msg = err ? err : "ruhvro_hip error";
+  if (err) rh_free_string(err);
+  PyObject* exc = PyExc_RuntimeError;
+  if (rc == RH_ERR_SCHEMA || rc == RH_ERR_DECODE) exc = PyExc_ValueError;   // src/lib.rs:25-27
+  else if (rc == RH_ERR_ARGUMENT) exc = PyExc_ValueError;
+  PyErr_SetString(exc, msg.c_str());
+  return nullptr;
+}
+
+PyObject* py_compile_schema(PyObject*, PyObject* args) {
+  const char* s;
+  Py_ssize_t n;
+  if (!PyArg_ParseTuple(args, "s#", &s, &n)) return nullptr;
+  char* err = nullptr;
+  rh_schema* h = rh_schema_compile(s, (size_t)n, &err);
+  if (!h) return raise_from(RH_ERR_SCHEMA, err);
+  return PyCapsule_New(h, kCapsule, capsule_free);
+}
+
+rh_schema* get_schema(PyObject* cap) {
+  return (rh_schema*)PyCapsule_GetPointer(cap, kCapsule);
+}
+
+PyObject* py_schema_ptr(PyObject*, PyObject* args) {
+  PyObject* cap;
+  if (!PyArg_ParseTuple(args, "O", &cap)) return nullptr;
+  rh_schema* s = get_schema(cap);
+  if (!s) return nullptr;
+  return PyLong_FromVoidPtr(s);
+}
+
+// export_schema(capsule) -> address of a malloc'd ArrowSchema (import with pyarrow, then free_struct)
+PyObject* py_export_schema(PyObject*, PyObject* args) {
+  PyObject* cap;
+  if (!PyArg_ParseTuple(args, "O", &cap)) return nullptr;
+  rh_schema* s = get_schema(cap);
+  if (!s) return nullptr;
+  ArrowSchema* out = (ArrowSchema*)std::calloc(1, sizeof(ArrowSchema));
+  if (rh_schema_export(s, out) != RH_OK) {
+    std::free(out);
+    PyErr_SetString(PyExc_RuntimeError, "schema export failed");
+    return nullptr;
+  }
+  return PyLong_FromVoidPtr(out);
+}
+
+PyObject* py_free_struct(PyObject*, PyObject* args) {
+  PyObject* addr;
+  if (!PyArg_ParseTuple(args, "O", &addr)) return nullptr;
+  void* p = PyLong_AsVoidPtr(addr);
+  if (!p && PyErr_Occurred()) return nullptr;
+  std::free(p);
+  Py_RETURN_NONE;
+}
+
+PyObject* stats_dict(const rh_stats& st) {
+  return Py_BuildValue("{s:K,s:K,s:K,s:I,s:I,s:f,s:f,s:f,s:f,s:f,s:f,s:f}", "records",
+                       (unsigned long long)st.records, "input_bytes", (unsigned long long)st.input_bytes,
+                       "output_bytes", (unsigned long long)st.output_bytes, "chunks", st.chunks, "blocks", st.blocks,
+                       "pack_ms", st.pack_ms, "h2d_ms", st.h2d_ms, "size_kernel_ms", st.size_kernel_ms,
+                       "scan_kernel_ms", st.scan_kernel_ms, "emit_kernel_ms", st.emit_kernel_ms, "d2h_ms", st.d2h_ms,
+                       "total_ms", st.total_ms);
+}
+
+// decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False)
+//   -> (list[int] addresses of malloc'd ArrowArray structs, stats dict | None)
+PyObject* py_decode(PyObject*, PyObject* args) {
+  PyObject *cap, *list;
+  unsigned long long num_chunks;
+  int device = -1;
+  unsigned long long stream = 0;
+  int want_stats = 0;
+  if (!PyArg_ParseTuple(args, "OOK|iKp", &cap, &list, &num_chunks, &device, &stream, &want_stats)) return nullptr;
+  rh_schema* s = get_schema(cap);
+  if (!s) return nullptr;
+  if (!PyList_Check(list)) {
+    PyErr_SetString(PyExc_TypeError, "argument 'list': expected a list of bytes");
+    return nullptr;
+  }
+  const Py_ssize_t n = PyList_GET_SIZE(list);
+  std::vector<const uint8_t*> ptrs((size_t)n);
+  std::vector<uint64_t> lens((size_t)n);
+  std::vector<PyObject*> keep;
+  keep.reserve((size_t)n);
+  bool ok = true;
+  for (Py_ssize_t i = 0; i < n; i++) {
+    PyObject* it = PyList_GET_ITEM(list, i);
+    if (PyBytes_Check(it)) {
+      Py_INCREF(it);
+    } else if (PyByteArray_Check(it)) {
+      it = PyBytes_FromStringAndSize(PyByteArray_AS_STRING(it), PyByteArray_GET_SIZE(it));   // copied, like PyBackedBytes
+      if (!it) { ok = false; break; }
+    } else {
+      PyErr_Format(PyExc_TypeError, "list element %zd: expected bytes, got %s", i, Py_TYPE(it)->tp_name);
+      ok = false;
+      break;
+    }
+    keep.push_back(it);
+    ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
+    lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
+  }
+  if (!ok) {
+    for (PyObject* o : keep) Py_DECREF(o);
+    return nullptr;
+  }
+  const uint32_t k = rh_clamp_chunks((uint64_t)n, num_chunks);
+  ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
+  rh_opts opts;
+  opts.device = device;
+  opts.flags = 0;
+  opts.stream = (void*)(uintptr_t)stream;
+  rh_stats st;
+  std::memset(&st, 0, sizeof st);
+  char* err = nullptr;
+  uint32_t out_k = 0;
+  int rc;
+  Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
+  rc = rh_decode(s, ptrs.data(), lens.data(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+  Py_END_ALLOW_THREADS
+  for (PyObject* o : keep) Py_DECREF(o);
+  if (rc != RH_OK) {
+    std::free(chunks);
+    return raise_from(rc, err);
+  }
+  PyObject* out = PyList_New(out_k);
+  for (uint32_t c = 0; c < out_k; c++) {
+    ArrowArray* one = (ArrowArray*)std::malloc(sizeof(ArrowArray));
+    std::memcpy(one, &chunks[c], sizeof(ArrowArray));
+    PyList_SET_ITEM(out, c, PyLong_FromVoidPtr(one));
+  }
+  std::free(chunks);
+  PyObject* stats = want_stats ? stats_dict(st) : (Py_INCREF(Py_None), Py_None);
+  PyObject* ret = PyTuple_Pack(2, out, stats);
+  Py_DECREF(out);
+  Py_DECREF(stats);
+  return ret;
+}
+
+// release_array(addr): release (if still owned) and free an ArrowArray shell pyarrow did not consume
+PyObject* py_release_array(PyObject*, PyObject* args) {
+  PyObject* addr;
+  if (!PyArg_ParseTuple(args, "O", &addr)) return nullptr;
+  ArrowArray* a = (ArrowArray*)PyLong_AsVoidPtr(addr);
+  if (!a && PyErr_Occurred()) return nullptr;
+  if (a) {
+    if (a->release) a->release(a);
+    std::free(a);
+  }
+  Py_RETURN_NONE;
+}
+
+PyObject* py_device_count(PyObject*, PyObject*) { return PyLong_FromLong(rh_device_count()); }
+
+PyMethodDef methods[] = {
+    {"compile_schema", py_compile_schema, METH_VARARGS, "compile_schema(json) -> schema capsule"},
+    {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
+    {"export_schema", py_export_schema, METH_VARARGS, "export_schema(capsule) -> address of ArrowSchema"},
+    {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False)"},
+    {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
+    {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
+    {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pyruhvro", "ruhvro_hip CPython boundary", -1, methods,
+                      nullptr, nullptr, nullptr, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__pyruhvro(void) { return PyModule_Create(&moddef); }

@@ -1,0 +1,71 @@
+"""Buffer-for-buffer comparison of two Arrow arrays / batches (test helper).
+
+``RecordBatch.equals`` is logical equality (it ignores e.g. an all-valid validity
+buffer vs an absent one); the parity bar for the GPU path is stricter: same
+buffers present, same meaningful bytes, same null counts -- the canonical form
+of arrow-rs builders described in oracle/assemble.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pyarrow as pa
+
+
+def _bytes(buf, n):
+    if n == 0:
+        return b""
+    assert buf is not None, "missing buffer"
+    assert buf.size >= n, f"buffer too small: {buf.size} < {n}"
+    return buf.to_pybytes()[:n]
+
+
+def _bits(buf, nbits):
+    raw = np.frombuffer(_bytes(buf, (nbits + 7) // 8), dtype=np.uint8)
+    return np.unpackbits(raw, bitorder="little")[:nbits]
+
+
+def assert_identical(a: pa.Array, b: pa.Array, path: str = "") -> None:
+    assert a.type == b.type, f"{path}: type {a.type} != {b.type}"
+    assert len(a) == len(b), f"{path}: length {len(a)} != {len(b)}"
+    assert a.offset == 0 and b.offset == 0, f"{path}: non-zero offset"
+    assert a.null_count == b.null_count, f"{path}: null_count {a.null_count} != {b.null_count}"
+    n = len(a)
+    t = a.type
+    ba, bb = a.buffers(), b.buffers()
+    if pa.types.is_null(t):
+        return
+    if not pa.types.is_union(t):
+        assert (ba[0] is None) == (bb[0] is None), f"{path}: validity presence {ba[0] is not None} != {bb[0] is not None}"
+        if ba[0] is not None:
+            assert np.array_equal(_bits(ba[0], n), _bits(bb[0], n)), f"{path}: validity bits differ"
+    if pa.types.is_boolean(t):
+        assert np.array_equal(_bits(ba[1], n), _bits(bb[1], n)), f"{path}: boolean values differ"
+    elif pa.types.is_string(t):
+        assert _bytes(ba[1], 4 * (n + 1)) == _bytes(bb[1], 4 * (n + 1)), f"{path}: string offsets differ"
+        last = int(np.frombuffer(_bytes(ba[1], 4 * (n + 1)), dtype=np.int32)[-1])
+        assert _bytes(ba[2], last) == _bytes(bb[2], last), f"{path}: string data differ"
+    elif pa.types.is_struct(t):
+        for i in range(t.num_fields):
+            assert_identical(a.field(i), b.field(i), f"{path}.{t.field(i).name}")
+    elif pa.types.is_union(t):
+        assert _bytes(ba[1], n) == _bytes(bb[1], n), f"{path}: type_ids differ"
+        for i in range(t.num_fields):
+            assert_identical(a.field(i), b.field(i), f"{path}<{t.field(i).name}>")
+    elif pa.types.is_map(t):
+        assert _bytes(ba[1], 4 * (n + 1)) == _bytes(bb[1], 4 * (n + 1)), f"{path}: map offsets differ"
+        assert_identical(a.keys, b.keys, f"{path}.keys")
+        assert_identical(a.items, b.items, f"{path}.values")
+    elif pa.types.is_list(t):
+        assert _bytes(ba[1], 4 * (n + 1)) == _bytes(bb[1], 4 * (n + 1)), f"{path}: list offsets differ"
+        assert_identical(a.values, b.values, f"{path}[]")
+    else:
+        w = t.bit_width // 8
+        assert _bytes(ba[1], w * n) == _bytes(bb[1], w * n), f"{path}: values differ"
+
+
+def assert_batches_identical(a: pa.RecordBatch, b: pa.RecordBatch) -> None:
+    assert a.schema.equals(b.schema, check_metadata=True), f"schema differs:\n{a.schema}\nvs\n{b.schema}"
+    assert a.num_rows == b.num_rows
+    for i, f in enumerate(a.schema):
+        assert_identical(a.column(i), b.column(i), f.name)
+    assert a.equals(b, check_metadata=True)
