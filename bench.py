@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- Avro -> Arrow direct decode on MI355X: records/s + achieved HBM GB/s.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (k_size -> k_scan -> k_emit, C ABI rh_decode_device) over one batch of
+synthetic Avro records that is ALREADY resident in HBM; the Arrow buffers are produced in HBM.  Workload
+(BASELINE.json config 4, the one the metric's target is quoted on): 10,000,000 records of the
+scripts/generate_avro.py schema, num_chunks = 8, per GPU (weak scaling: rank r decodes rows
+[r*10M, (r+1)*10M) of the seeded stream; no data-path collective -- records are independent).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      k_emit (the dominant kernel): algorithmic bytes per launch / its mean launch duration,
+                measured with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM.
+  cpu_baseline  the oracle's C restatement of the reference walker ("port"), reference threading shape
+                (serial pack + one thread per chunk, 8 chunks), timed on this box's host cores on a
+                bounded sample of the same workload.  Reported, not targeted.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WORKLOADS = {
+    # name: (generator config, records per GPU, num_chunks, description)
+    "full10m": ("full", 10_000_000, 8, "10M records of the generate_avro.py schema (BASELINE.json config 4), num_chunks=8"),
+    "full1m": ("full", 1_000_000, 8, "1M records of the generate_avro.py schema, num_chunks=8"),
+    "cfg3_1m": ("cfg3", 1_000_000, 8, "1M string + nullable-union + enum records (BASELINE.json config 3)"),
+    "flat4_1m": ("flat4", 1_000_000, 8, "1M flat-primitive records (BASELINE.json config 2)"),
+}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="full10m", choices=sorted(WORKLOADS))
+    ap.add_argument("--records", type=int, default=0, help="override records per GPU (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    return ap.parse_args(argv)
+
+
+def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int):
+    """Oracle C walker with the reference's threading shape, bounded sample, best of 3."""
+    from avrogen import fastgen
+    from oracle import c_walker
+    data, offsets = fastgen.generate(gen_cfg, n_sample)
+    cs = c_walker.CompiledSchema(schema_json)
+    c_walker.decode_packed(cs, data, offsets, num_chunks, threaded=True, materialize=False)   # warm-up
+    best = float("inf")
+    for _ in range(3):
+        t = time.perf_counter()
+        c_walker.decode_packed(cs, data, offsets, num_chunks, threaded=True, materialize=False)
+        best = min(best, time.perf_counter() - t)
+    return {
+        "value": n_sample / best, "unit": "records/s", "cores": num_chunks, "kind": "port",
+        "sample": f"{n_sample} records of the same workload, {num_chunks} chunks = {num_chunks} threads "
+                  f"(reference shape: serial pack + one task per chunk), best of 3; host has {os.cpu_count()} cpus",
+    }
+
+
+def run(args, make_step=None, backend="nccl"):
+    """Timed loop shared by the real bench and the gloo CPU test (which injects `make_step`)."""
+    import torch
+    import torch.distributed as dist
+    from pyruhvro_amd import dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        rdist.init_process_group(backend)
+    use_cuda = backend == "nccl"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+
+    gen_cfg, n, num_chunks, desc = WORKLOADS[args.workload]
+    if args.records:
+        n = args.records
+    lo, _ = rdist.shard_rows(n, rank)
+    step, info = make_step(gen_cfg, n, lo, num_chunks, dev, local_rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if use_cuda:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0}
+    for _ in range(args.steps):
+        st = step()
+        for k in acc:
+            acc[k] += st.get(k, 0.0)
+    sync()
+    wall = time.perf_counter() - t0
+    wall = rdist.max_over_ranks(wall, dev)
+
+    local = {"records": n, "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
+             "step_ms": wall * 1e3 / args.steps}
+    for k in acc:
+        local[k] = acc[k] / max(args.steps, 1)
+    per_rank = rdist.gather_stats(local, dev)
+    agg = rdist.aggregate(per_rank, args.steps, wall)
+    return rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc)
+
+
+def gpu_step_factory(gen_cfg, n, row_lo, num_chunks, dev, local_rank):
+    import numpy as np
+    import torch
+    from avrogen import fastgen
+    from avrogen.schemas import SCHEMAS
+    from pyruhvro_amd import cabi
+
+    data, offsets = fastgen.generate(gen_cfg, n, start=row_lo)
+    d_data = torch.empty(len(data) + 64, dtype=torch.uint8, device=dev)
+    d_data[: len(data)].copy_(torch.from_numpy(data))
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    schema = SCHEMAS[gen_cfg]
+    stream = torch.cuda.current_stream().cuda_stream
+    data_len = int(offsets[-1])
+    info = {"input_bytes": data_len, "output_bytes": 0}
+
+    def step():
+        r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
+                               device=local_rank, stream=stream)
+        info["output_bytes"] = r.output_bytes
+        st = r.stats
+        r.free()
+        return st
+
+    step.keepalive = (d_data, d_off)
+    first = step()      # also fills output_bytes
+    assert first["records"] == n
+    return step, info
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch  # noqa: F401  (first: our library must share torch's HIP runtime)
+    from avrogen.schemas import SCHEMAS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc) = run(args, gpu_step_factory, "nccl")
+    if rank != 0:
+        return
+    r0 = per_rank[0]
+    b_in, b_out = r0["input_bytes"], r0["output_bytes"]
+    alg_bytes = b_in + 8 * n + b_out                       # B_in + 8 (u64 offset) + B_out per record
+    emit_ms = agg["emit_kernel_ms_max"]
+    achieved = alg_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
+    path_ms = r0["size_kernel_ms"] + r0["scan_kernel_ms"] + r0["emit_kernel_ms"]
+    out = {
+        "metric": "Avro records/sec -> Arrow (direct decode, input and output resident in HBM)",
+        "value": agg["records_per_s"],
+        "unit": "records/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic (seeded generator with scripts/generate_avro.py's distributions; Faker unavailable)",
+        "config": {"workload": desc, "records_per_gpu": n, "num_chunks": num_chunks,
+                   "schema": gen_cfg, "input_bytes_per_gpu": int(b_in), "arrow_bytes_per_gpu": int(b_out),
+                   "parallelism": f"{world} x independent shard (no data-path collective)",
+                   "kernel_ms": {"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
+                   "path_kernel_ms": path_ms,
+                   "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
+        "roofline": {"bound": "hbm", "kernel": "rh_k_emit", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "bytes_per_record": alg_bytes / n, "avg_launch_ms": emit_ms},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n), num_chunks)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

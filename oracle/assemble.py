@@ -49,8 +49,13 @@ def _validity(b: Buffers, always: bool):
         return None, 0
     v = np.asarray(b.valid, dtype=bool)
     nulls = int(v.size - np.count_nonzero(v))
-    if always or nulls > 0:
+    if nulls > 0:
         return _bitmap(v), nulls
+    if always:
+        # Arrow C++ drops a validity buffer handed over with null_count == 0 (ArrayData::Make);
+        # null_count = -1 ("unknown") keeps the always-present bitmap of nullable struct/list/map,
+        # which is what pyarrow holds after importing arrow-rs' arrays over the C Data Interface.
+        return _bitmap(v), -1
     return None, 0
 
 

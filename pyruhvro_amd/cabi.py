@@ -1,0 +1,210 @@
+"""ctypes view of the C ABI in include/ruhvro_hip.h (libruhvro_hip.so).
+
+Used by bench.py (device-resident decode on torch-owned memory), by the
+packed-input Python entry point, and by the tests that exercise the ABI
+directly.  Nothing here decodes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libruhvro_hip.so")
+
+RH_OK, RH_ERR_SCHEMA, RH_ERR_DECODE, RH_ERR_RUNTIME, RH_ERR_ARGUMENT = range(5)
+
+
+class RhOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p)]
+
+
+class RhStats(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64),
+                ("chunks", C.c_uint32), ("blocks", C.c_uint32), ("pack_ms", C.c_float), ("h2d_ms", C.c_float),
+                ("size_kernel_ms", C.c_float), ("scan_kernel_ms", C.c_float), ("emit_kernel_ms", C.c_float),
+                ("d2h_ms", C.c_float), ("total_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64),
+                       ("n_buffers", C.c_int64), ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+                       ("children", C.POINTER(C.POINTER(ArrowArray))), ("dictionary", C.POINTER(ArrowArray)),
+                       ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowSchema(C.Structure):
+    pass
+
+
+ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64),
+                        ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(ArrowSchema))),
+                        ("dictionary", C.POINTER(ArrowSchema)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class ArrowDeviceArray(C.Structure):
+    _fields_ = [("array", ArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32),
+                ("sync_event", C.c_void_p), ("reserved", C.c_int64 * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libruhvro_hip.so (raises OSError if it was not built -- there is no fallback)."""
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.rh_schema_compile.restype = C.c_void_p
+        L.rh_schema_compile.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p)]
+        L.rh_schema_free.argtypes = [C.c_void_p]
+        L.rh_schema_export.argtypes = [C.c_void_p, C.POINTER(ArrowSchema)]
+        L.rh_clamp_chunks.restype = C.c_uint32
+        L.rh_clamp_chunks.argtypes = [C.c_uint64, C.c_uint64]
+        L.rh_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(RhOpts),
+                                C.POINTER(ArrowArray), C.POINTER(C.c_uint32), C.POINTER(RhStats), C.POINTER(C.c_char_p)]
+        L.rh_decode_packed.argtypes = L.rh_decode.argtypes
+        L.rh_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.POINTER(RhOpts), C.POINTER(C.c_void_p), C.POINTER(RhStats),
+                                       C.POINTER(C.c_char_p)]
+        L.rh_device_result_chunks.restype = C.c_uint32
+        L.rh_device_result_chunks.argtypes = [C.c_void_p]
+        L.rh_device_result_output_bytes.restype = C.c_uint64
+        L.rh_device_result_output_bytes.argtypes = [C.c_void_p]
+        L.rh_device_result_export.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ArrowDeviceArray)]
+        L.rh_device_result_to_host.argtypes = [C.c_void_p, C.POINTER(ArrowArray), C.POINTER(C.c_char_p)]
+        L.rh_device_result_free.argtypes = [C.c_void_p]
+        L.rh_free_string.argtypes = [C.c_void_p]
+        L.rh_abi_version.restype = C.c_int
+        L.rh_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _take_err(err: C.c_char_p) -> str:
+    msg = err.value.decode("utf-8", "replace") if err.value else "ruhvro_hip error"
+    if err.value is not None:
+        lib().rh_free_string(C.cast(err, C.c_void_p))
+    return msg
+
+
+def _raise(rc: int, err: C.c_char_p):
+    msg = _take_err(err)
+    if rc in (RH_ERR_SCHEMA, RH_ERR_DECODE, RH_ERR_ARGUMENT):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+class Schema:
+    """Compiled schema handle (rh_schema*) + the pyarrow schema of its batches."""
+
+    _cache: dict = {}
+
+    def __init__(self, schema_json: str):
+        L = lib()
+        raw = schema_json.encode()
+        err = C.c_char_p()
+        self.handle = L.rh_schema_compile(raw, len(raw), C.byref(err))
+        if not self.handle:
+            _raise(RH_ERR_SCHEMA, err)
+        cs = ArrowSchema()
+        if L.rh_schema_export(self.handle, C.byref(cs)) != RH_OK:
+            raise RuntimeError("rh_schema_export failed")
+        st = pa.DataType._import_from_c(C.addressof(cs))
+        self.arrow_schema = pa.schema(list(st))
+
+    @classmethod
+    def get(cls, schema_json: str) -> "Schema":
+        s = cls._cache.get(schema_json)
+        if s is None:
+            s = cls._cache[schema_json] = cls(schema_json)
+        return s
+
+
+def _import_chunks(arr, k: int, schema: pa.Schema) -> List[pa.RecordBatch]:
+    return [pa.RecordBatch._import_from_c(C.addressof(arr[i]), schema) for i in range(k)]
+
+
+def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_chunks: int,
+                  device: int = -1, want_stats: bool = False):
+    """rh_decode_packed: one contiguous payload + u64 offsets (host memory) -> list[RecordBatch]."""
+    L = lib()
+    s = Schema.get(schema_json)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    k = L.rh_clamp_chunks(n, num_chunks)
+    arr = (ArrowArray * k)()
+    out_k = C.c_uint32()
+    st = RhStats()
+    err = C.c_char_p()
+    opts = RhOpts(device, 0, None)
+    rc = L.rh_decode_packed(s.handle, data.ctypes.data, offsets.ctypes.data, n, num_chunks, C.byref(opts), arr,
+                            C.byref(out_k), C.byref(st), C.byref(err))
+    if rc != RH_OK:
+        _raise(rc, err)
+    out = _import_chunks(arr, out_k.value, s.arrow_schema)
+    return (out, st.as_dict()) if want_stats else out
+
+
+class DeviceResult:
+    """Owns an rh_device_result (Arrow buffers resident in HBM)."""
+
+    def __init__(self, handle, schema: Schema, stats: dict):
+        self.handle = handle
+        self.schema = schema
+        self.stats = stats
+
+    @property
+    def chunks(self) -> int:
+        return lib().rh_device_result_chunks(self.handle)
+
+    @property
+    def output_bytes(self) -> int:
+        return lib().rh_device_result_output_bytes(self.handle)
+
+    def to_host(self) -> List[pa.RecordBatch]:
+        k = self.chunks
+        arr = (ArrowArray * k)()
+        err = C.c_char_p()
+        rc = lib().rh_device_result_to_host(self.handle, arr, C.byref(err))
+        if rc != RH_OK:
+            _raise(rc, err)
+        return _import_chunks(arr, k, self.schema.arrow_schema)
+
+    def free(self):
+        if self.handle:
+            lib().rh_device_result_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
+                  device: int = -1, stream: int = 0, want_stats: bool = True) -> DeviceResult:
+    """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr())."""
+    L = lib()
+    s = Schema.get(schema_json)
+    out = C.c_void_p()
+    st = RhStats()
+    err = C.c_char_p()
+    opts = RhOpts(device, 0, stream or None)
+    rc = L.rh_decode_device(s.handle, d_data, d_offsets, data_len, n, num_chunks, C.byref(opts), C.byref(out),
+                            C.byref(st) if want_stats else None, C.byref(err))
+    if rc != RH_OK:
+        _raise(rc, err)
+    return DeviceResult(out.value, s, st.as_dict())

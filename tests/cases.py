@@ -1,0 +1,219 @@
+"""Shared test inputs: (schema JSON, list[bytes]) cases for the oracle tests (CPU)
+and the GPU parity tests.
+
+  differential_cases()  the reference's differential tests restated with the same
+                        schemas and value formulas (ruhvro/src/fast_decode.rs:1008-1231)
+                        plus the expected Python values;
+  wire_cases()          valid-but-unusual wire forms the reference accepts (F4/F5 of
+                        SURVEY.md, fast_decode.rs:689-700,825-828);
+  error_cases()         malformed datums + the exact message the reference raises
+                        (fast_decode.rs:575,591,646,849,866,874,884,898,906,910);
+  nesting_cases()       schemas the reference never tests (union-of-record, list of
+                        lists, nullable containers, children domains with bitmaps).
+"""
+from __future__ import annotations
+
+import json
+import struct
+from typing import List, Tuple
+
+from avrogen.encoder import Blocks, Branch, to_datum, zigzag
+from avrogen.schemas import SCHEMAS
+from oracle.avro_schema import parse_schema
+
+
+def _enc(schema_json: str, values) -> List[bytes]:
+    s = parse_schema(schema_json)
+    return [to_datum(s, v) for v in values]
+
+
+def differential_cases():
+    """-> list of (name, schema_json, records, expected_pylist)."""
+    out = []
+    f32 = lambda x: struct.unpack("<f", struct.pack("<f", x))[0]  # noqa: E731
+    # decodes_flat_primitives, fast_decode.rs:1008-1030
+    vals = [{"i": i, "l": i * 100, "f": f32(i * 1.5), "d": i * 2.25, "b": i % 2 == 0, "s": f"row-{i}"} for i in range(5)]
+    out.append(("flat_primitives", SCHEMAS["flat_primitives"], _enc(SCHEMAS["flat_primitives"], vals), vals))
+    # decodes_nullable_primitives, 1033-1057 (both null orders)
+    vals = [{"i": i if i % 2 == 0 else None, "s": None if i % 3 == 0 else f"v-{i}"} for i in range(6)]
+    out.append(("nullable_primitives", SCHEMAS["t_nullable"], _enc(SCHEMAS["t_nullable"], vals), vals))
+    # decodes_enum, 1079-1092
+    vals = [{"e": "ABC"[i % 3]} for i in range(6)]
+    out.append(("enum", SCHEMAS["t_enum"], _enc(SCHEMAS["t_enum"], vals), vals))
+    # decodes_nested_record, 1095-1116
+    vals = [{"outer_id": i, "inner": {"x": i, "label": f"lbl-{i}"}} for i in range(5)]
+    out.append(("nested_record", SCHEMAS["t_nested"], _enc(SCHEMAS["t_nested"], vals), vals))
+    # decodes_nullable_nested_record, 1119-1144
+    vals = [{"inner": {"x": i} if i % 2 == 0 else None} for i in range(6)]
+    out.append(("nullable_nested_record", SCHEMAS["t_nullable_nested"], _enc(SCHEMAS["t_nullable_nested"], vals), vals))
+    # decodes_multi_variant_union, 1147-1165
+    vals = []
+    for i in range(8):
+        vals.append({"u": [None, f"s-{i}", i * 11, i % 8 == 3][i % 4]})
+    out.append(("multi_variant_union", SCHEMAS["t_union"], _enc(SCHEMAS["t_union"], vals), vals))
+    # decodes_array_of_string, 1168-1184
+    vals = [{"tags": [f"t-{i}-a", f"t-{i}-b"]} for i in range(6)]
+    out.append(("array_of_string", SCHEMAS["t_array_str"], _enc(SCHEMAS["t_array_str"], vals), vals))
+    # decodes_empty_array, 1187-1199
+    vals = [{"tags": []} for _ in range(3)]
+    out.append(("empty_array", SCHEMAS["t_array_int"], _enc(SCHEMAS["t_array_int"], vals), vals))
+    # decodes_map_of_string, 1202-1231 (wire order preserved on the fast path)
+    vals = [{"props": [(f"k{i}-1", f"v{i}-1"), (f"k{i}-2", f"v{i}-2")]} for i in range(4)]
+    out.append(("map_of_string", SCHEMAS["t_map_str"], _enc(SCHEMAS["t_map_str"], vals), vals))
+    # test_enum, deserialize.rs:312-354 (the one value-level assert the reference has on decode output)
+    vals = [{"a": 27, "b": "foo", "c": "clubs"}, {"a": 28, "b": "bar", "c": "hearts"}]
+    out.append(("test_enum", SCHEMAS["kat_enum"], _enc(SCHEMAS["kat_enum"], vals), vals))
+    return out
+
+
+def logical_case():
+    """decodes_logical_types, fast_decode.rs:1060-1076 -> (schema, records, expected raw ints)."""
+    vals = [{"d": i * 7, "tm": 1_700_000_000_000 + i, "tu": 1_700_000_000_000_000 + i} for i in range(4)]
+    return SCHEMAS["t_logical"], _enc(SCHEMAS["t_logical"], vals), vals
+
+
+def wire_cases():
+    """-> list of (name, schema_json, records).  All valid for the reference's fast path."""
+    out = []
+    s_arr = SCHEMAS["t_array_str"]
+    sa = parse_schema(s_arr)
+    recs = [
+        to_datum(sa, {"tags": Blocks([(["a", "bb"], True), (["ccc"], False), (["d"], True)])}),  # negative counts + byte sizes, multi-block
+        to_datum(sa, {"tags": Blocks([(["x"] * 70, False), (["y"] * 3, True)])}),
+        to_datum(sa, {"tags": []}),
+        to_datum(sa, {"tags": ["solo"]}) + b"\xde\xad\xbe\xef",            # trailing bytes are ignored (fast_decode.rs:825-828)
+    ]
+    out.append(("array_blocks", s_arr, recs))
+    s_map = SCHEMAS["t_map_str"]
+    sm = parse_schema(s_map)
+    recs = [
+        to_datum(sm, {"props": Blocks([([("k1", "v1")], True), ([("k2", "v2"), ("k1", "dup")], False)])}),
+        to_datum(sm, {"props": []}),
+        to_datum(sm, {"props": [("", "")]}),
+    ]
+    out.append(("map_blocks", s_map, recs))
+    # [T, "null"] ordering next to ["null", T]
+    recs = _enc(SCHEMAS["t_nullable"], [{"i": None, "s": None}, {"i": -1, "s": ""}, {"i": 2**31 - 1, "s": "x" * 300}])
+    out.append(("null_orders", SCHEMAS["t_nullable"], recs))
+    # int truncation (`as i32`) and extreme longs / NaN payloads
+    s = json.dumps({"type": "record", "name": "X", "fields": [
+        {"name": "i", "type": "int"}, {"name": "l", "type": "long"},
+        {"name": "f", "type": "float"}, {"name": "d", "type": "double"}]})
+    raw = []
+    for iv, lv, fb, db in [(2**31 + 5, 2**63 - 1, 0x7FC00001, 0x7FF8000000000123), (-2**31 - 7, -2**63, 0xFF800000, 0x8000000000000000),
+                           (2**40 + 3, 0, 0x00000001, 0x0000000000000001)]:
+        raw.append(zigzag(iv) + zigzag(lv) + struct.pack("<I", fb) + struct.pack("<Q", db))
+    # 10-byte varint whose high bits are dropped (fast_decode.rs:860: bits past 63 vanish)
+    raw.append(b"\x02" + b"\xff" * 9 + b"\x7f" + struct.pack("<f", 1.5) + struct.pack("<d", -2.5))
+    out.append(("extremes", s, raw))
+    # empty strings, long strings
+    recs = _enc(SCHEMAS["flat_primitives"], [
+        {"i": 0, "l": 0, "f": 0.0, "d": 0.0, "b": False, "s": ""},
+        {"i": -1, "l": -1, "f": -1.0, "d": -1.0, "b": True, "s": "é" * 1000},
+        {"i": 1, "l": 1, "f": 1.0, "d": 1.0, "b": True, "s": "z" * 70000}])
+    out.append(("strings", SCHEMAS["flat_primitives"], recs))
+    return out
+
+
+def error_cases():
+    """-> list of (name, schema_json, good_prefix_records, bad_record, message)."""
+    out = []
+    sj = SCHEMAS["flat_primitives"]
+    s = parse_schema(sj)
+    good = to_datum(s, {"i": 1, "l": 2, "f": 1.0, "d": 2.0, "b": True, "s": "ok"})
+    goods = [good] * 3
+    out.append(("eob_varint", sj, goods, b"", "unexpected end of buffer"))
+    out.append(("eob_mid_varint", sj, goods, b"\x80", "unexpected end of buffer"))
+    out.append(("varint_too_long", sj, goods, b"\x80" * 10 + b"\x00", "zigzag varint too long"))
+    out.append(("eob_f32", sj, goods, zigzag(1) + zigzag(2) + b"\x00\x00", "unexpected end of buffer (f32)"))
+    out.append(("eob_f64", sj, goods, zigzag(1) + zigzag(2) + b"\x00" * 4 + b"\x00" * 7, "unexpected end of buffer (f64)"))
+    out.append(("bad_bool", sj, goods, zigzag(1) + zigzag(2) + b"\x00" * 12 + b"\x07", "invalid boolean byte: 7"))
+    out.append(("eob_bool", sj, goods, zigzag(1) + zigzag(2) + b"\x00" * 12, "unexpected end of buffer"))
+    out.append(("neg_strlen", sj, goods, zigzag(1) + zigzag(2) + b"\x00" * 12 + b"\x01" + zigzag(-3), "negative string length"))
+    out.append(("eob_string", sj, goods, zigzag(1) + zigzag(2) + b"\x00" * 12 + b"\x01" + zigzag(10) + b"abc",
+                "unexpected end of buffer (string)"))
+    se = SCHEMAS["t_enum"]
+    ge = [b"\x00", b"\x02", b"\x04"]
+    out.append(("enum_oor", se, ge, zigzag(3), "enum index 3 out of range"))
+    out.append(("enum_negative", se, ge, zigzag(-1), "enum index 18446744073709551615 out of range"))
+    sn = SCHEMAS["t_nullable"]
+    gn = _enc(sn, [{"i": 1, "s": "a"}, {"i": None, "s": None}])
+    out.append(("bad_branch", sn, gn, zigzag(2), "invalid union branch index: 2"))
+    out.append(("bad_branch_neg", sn, gn, zigzag(-1), "invalid union branch index: -1"))
+    su = SCHEMAS["t_union"]
+    gu = _enc(su, [{"u": None}, {"u": "x"}, {"u": 3}, {"u": True}])
+    out.append(("union_oor", su, gu, zigzag(4), "union branch index out of range: 4"))
+    out.append(("union_neg", su, gu, zigzag(-2), "union branch index out of range: -2"))
+    sa = SCHEMAS["t_array_str"]
+    ga = _enc(sa, [{"tags": ["a"]}, {"tags": []}])
+    out.append(("array_unterminated", sa, ga, zigzag(1) + zigzag(1) + b"a", "unexpected end of buffer"))
+    out.append(("array_huge_count", sa, ga, zigzag(2**40) + zigzag(1) + b"a", "unexpected end of buffer"))
+    out.append(("array_item_eob", sa, ga, zigzag(2) + zigzag(1) + b"a" + zigzag(5) + b"ab", "unexpected end of buffer (string)"))
+    return out
+
+
+def nesting_cases():
+    """Schemas beyond the reference's own tests; expected values come from the oracle."""
+    out = []
+    # record / array / map as variants of an N-variant union; enum variant named by its fullname
+    s = json.dumps({"type": "record", "name": "U", "namespace": "ns.x", "fields": [
+        {"name": "u", "type": ["null", {"type": "record", "name": "R", "fields": [
+            {"name": "a", "type": "int"}, {"name": "b", "type": ["null", "string"]}]},
+            {"type": "array", "items": "long"}, {"type": "enum", "name": "E", "symbols": ["X", "YY"]}, "double"]},
+        {"name": "tail", "type": "boolean"}]})
+    vals = []
+    for i in range(40):
+        m = i % 6
+        u = [None, {"a": i, "b": None}, {"a": -i, "b": f"b{i}"}, list(range(i % 5)), Branch(3, i % 2), float(i) / 3][m]
+        vals.append({"u": u, "tail": i % 3 == 0})
+    out.append(("union_of_containers", s, _enc(s, vals)))
+    # list of lists of nullable strings, list of nullable records with bools (child-domain bitmaps)
+    s = json.dumps({"type": "record", "name": "N", "fields": [
+        {"name": "ll", "type": {"type": "array", "items": {"type": "array", "items": ["null", "string"]}}},
+        {"name": "lr", "type": {"type": "array", "items": ["null", {"type": "record", "name": "Q", "fields": [
+            {"name": "flag", "type": "boolean"}, {"name": "v", "type": ["null", "int"]},
+            {"name": "m", "type": {"type": "map", "values": ["null", "boolean"]}}]}]}},
+        {"name": "id", "type": "int"}]})
+    vals = []
+    for i in range(60):
+        ll = [[None if (i + j + k) % 3 == 0 else f"s{i}-{j}-{k}" for k in range((i + j) % 4)] for j in range(i % 3)]
+        lr = [None if (i + j) % 4 == 0 else {"flag": (i + j) % 2 == 0, "v": None if j % 2 else i * j,
+                                             "m": [(f"k{j}{t}", [None, True, False][(i + t) % 3]) for t in range(j % 3)]}
+              for j in range(i % 5)]
+        vals.append({"ll": ll, "lr": lr, "id": i})
+    out.append(("nested_lists", s, _enc(s, vals)))
+    # nullable array, [T,"null"] order, nullable enum, date/timestamps nullable.  (A nullable MAP cannot be
+    # translated by the reference at all: default_field_name panics on Map, schema_translate.rs:88,148,212.)
+    s = json.dumps({"type": "record", "name": "C", "fields": [
+        {"name": "na", "type": ["null", {"type": "array", "items": "int"}]},
+        {"name": "ne", "type": ["null", {"type": "enum", "name": "E2", "symbols": ["p", "qq", "rrr"]}]},
+        {"name": "nd", "type": ["null", {"type": "int", "logicalType": "date"}]},
+        {"name": "nt", "type": [{"type": "long", "logicalType": "timestamp-micros"}, "null"]},
+        {"name": "nf", "type": ["null", "float"]}, {"name": "nb", "type": ["boolean", "null"]}]})
+    vals = []
+    for i in range(50):
+        vals.append({"na": None if i % 3 == 0 else list(range(i % 4)),
+                     "ne": None if i % 5 == 0 else ["p", "qq", "rrr"][i % 3],
+                     "nd": None if i % 2 else i * 100, "nt": None if i % 3 == 2 else 1_700_000_000_000_000 + i,
+                     "nf": None if i % 7 == 0 else float(i) * 0.5, "nb": None if i % 4 == 3 else i % 2 == 0})
+    out.append(("nullable_containers", s, _enc(s, vals)))
+    # deep nullable nesting: null-fill must cascade through records, unions and lists
+    s = json.dumps({"type": "record", "name": "D", "fields": [
+        {"name": "o", "type": ["null", {"type": "record", "name": "O1", "fields": [
+            {"name": "p", "type": ["null", {"type": "record", "name": "O2", "fields": [
+                {"name": "u", "type": ["null", "int", "string"]},
+                {"name": "arr", "type": {"type": "array", "items": "string"}},
+                {"name": "plain", "type": {"type": "record", "name": "O3", "fields": [
+                    {"name": "z", "type": "long"}, {"name": "e", "type": {"type": "enum", "name": "E3", "symbols": ["a", "b"]}}]}}]}]},
+            {"name": "q", "type": "double"}]}]}]})
+    vals = []
+    for i in range(45):
+        if i % 3 == 0:
+            o = None
+        else:
+            p = None if i % 4 == 1 else {"u": [None, i, f"u{i}"][i % 3], "arr": [f"a{i}"] * (i % 3),
+                                         "plain": {"z": i * 1000, "e": "ab"[i % 2]}}
+            o = {"p": p, "q": i / 7}
+        vals.append({"o": o})
+    out.append(("deep_nullfill", s, _enc(s, vals)))
+    return out

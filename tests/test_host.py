@@ -1,0 +1,168 @@
+"""Host-side logic of the engine, no GPU needed: schema front-end vs the oracle, the C ABI surface,
+the Python boundary's argument handling, and the loud failure without a device."""
+import ctypes as C
+import json
+import os
+import re
+
+import pyarrow as pa
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import cases
+from avrogen.schemas import SCHEMAS
+from oracle import avro_schema as S
+
+import pyruhvro_amd as P
+from pyruhvro_amd import cabi
+from conftest import ROOT, has_gpu
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ruhvro_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(rh_[a-z_]+)\s*\(", hdr))
+    assert {"rh_schema_compile", "rh_decode", "rh_decode_packed", "rh_decode_device", "rh_schema_export"} <= names
+    lib = C.CDLL(cabi.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), f"libruhvro_hip.so does not export {n}"
+    assert cabi.lib().rh_abi_version() == 1
+
+
+def test_clamp_chunks_matches_reference():   # deserialize.rs:53-55
+    f = cabi.lib().rh_clamp_chunks
+    assert [f(10, k) for k in (0, 1, 3, 10, 11, 1000)] == [1, 1, 3, 10, 10, 10]
+    assert f(0, 0) == 1 and f(0, 8) == 1 and f(1, 8) == 1
+
+
+@pytest.mark.parametrize("name", sorted(SCHEMAS))
+def test_arrow_schema_matches_oracle(name):
+    got = P.arrow_schema(SCHEMAS[name])
+    exp = S.to_arrow_schema(S.parse_schema(SCHEMAS[name]))
+    assert got.equals(exp, check_metadata=True), f"{got}\n!=\n{exp}"
+
+
+def test_arrow_schema_nesting_cases_and_metadata():
+    for _, schema, _ in cases.nesting_cases():
+        assert P.arrow_schema(schema).equals(S.to_arrow_schema(S.parse_schema(schema)), check_metadata=True)
+    js = json.dumps({"type": "record", "name": "T", "namespace": "a.b", "fields": [
+        {"name": "r", "type": {"type": "record", "name": "R", "doc": "rdoc", "aliases": ["Old", "x.Y"], "fields": [
+            {"name": "f", "type": "int", "doc": "fdoc"}, {"name": "g", "type": ["null", "R2x"] if False else "long"}]}},
+        {"name": "u", "type": ["int", {"type": "enum", "name": "E", "symbols": ["s"], "doc": "ignored"}]},
+        {"name": "e", "type": {"type": "enum", "name": "c.d.E2", "symbols": ["s"], "doc": "dropped"}}]})
+    got = P.arrow_schema(js)
+    assert got.equals(S.to_arrow_schema(S.parse_schema(js)), check_metadata=True)
+    assert got.field("r").metadata == {b"avro::doc": b"rdoc", b"avro::aliases": b"[a.b.Old,x.Y]"}
+    assert got.field("e").metadata is None
+
+
+BAD_SCHEMAS = [
+    ("not json", "Failed to parse schema"),
+    ('"string"', "record"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":"bytes"}]}', "bytes"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f","size":4}}]}', "fixed"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"int","logicalType":"time-millis"}}]}', "time-millis"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"string","logicalType":"uuid"}}]}', "uuid"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":"nosuchtype"}]}', "Unknown type"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"record","name":"y","fields":[]}},{"name":"b","type":"y"}]}', ""),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":["null",{"type":"map","values":"int"}]}]}', "Map support"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":["int","int"]}]}', "duplicate"),
+    ('{"type":"record","name":"x","fields":[]}', "0 fields"),
+]
+
+
+@pytest.mark.parametrize("schema,frag", BAD_SCHEMAS)
+def test_bad_schema_is_value_error(schema, frag):
+    with pytest.raises(ValueError) as ei:          # src/lib.rs:25-27,52: parse failure -> ValueError
+        P.arrow_schema(schema)
+    assert frag.lower() in str(ei.value).lower()
+    with pytest.raises(ValueError):
+        S.build_tree(S.parse_schema(schema))       # the oracle rejects the same documents
+
+
+# ---- random schemas: product's translation == oracle's -------------------------------------------
+_prims = st.sampled_from(["int", "long", "float", "double", "boolean", "string",
+                          {"type": "int", "logicalType": "date"}, {"type": "long", "logicalType": "timestamp-millis"},
+                          {"type": "long", "logicalType": "timestamp-micros"}])
+
+
+def _types(depth, counter):
+    def named(kind):
+        counter[0] += 1
+        return f"{kind}{counter[0]}"
+    if depth <= 0:
+        return _prims
+    sub = st.deferred(lambda: _types(depth - 1, counter))
+    rec = st.lists(sub, min_size=1, max_size=3).map(
+        lambda ts: {"type": "record", "name": named("R"), "fields": [{"name": f"f{i}", "type": t} for i, t in enumerate(ts)]})
+    enum = st.lists(st.sampled_from(["A", "B", "CC", "DDD"]), min_size=1, max_size=3, unique=True).map(
+        lambda sy: {"type": "enum", "name": named("E"), "symbols": sy})
+    arr = sub.map(lambda t: {"type": "array", "items": t})
+    mp = sub.map(lambda t: {"type": "map", "values": t})
+    return st.one_of(_prims, rec, enum, arr, mp)
+
+
+@st.composite
+def schemas(draw):
+    counter = [0]
+    base = _types(2, counter)
+
+    def wrap(t):
+        mode = draw(st.integers(0, 3))
+        is_map = isinstance(t, dict) and t.get("type") == "map"
+        if mode == 1 and not is_map:
+            return ["null", t]
+        if mode == 2 and not is_map:
+            return [t, "null"]
+        if mode == 3 and not is_map:
+            return ["null", t, "boolean"] if t not in ("boolean",) else ["null", t, "int"]
+        return t
+    n = draw(st.integers(1, 4))
+    fields = [{"name": f"c{i}", "type": wrap(draw(base))} for i in range(n)]
+    return json.dumps({"type": "record", "name": "Top", "namespace": draw(st.sampled_from(["", "ns", "a.b"])), "fields": fields})
+
+
+@settings(max_examples=150, deadline=None)
+@given(schemas())
+def test_random_schema_translation(js):
+    try:
+        exp = S.to_arrow_schema(S.parse_schema(js))
+        S.build_tree(S.parse_schema(js))
+    except S.SchemaError:
+        with pytest.raises(ValueError):
+            P.arrow_schema(js)
+        return
+    got = P.arrow_schema(js)
+    assert got.equals(exp, check_metadata=True), f"{js}\n{got}\n!=\n{exp}"
+
+
+# ---- Python boundary -----------------------------------------------------------------------------
+def test_argument_errors_without_touching_the_gpu():
+    with pytest.raises(TypeError):
+        P.deserialize_array_threaded("notalist", SCHEMAS["flat4"], 2)
+    with pytest.raises(TypeError):
+        P.deserialize_array_threaded([b"\x00", "str"], SCHEMAS["flat4"], 2)       # non-bytes element
+    with pytest.raises(TypeError):
+        P.deserialize_array_threaded([b"\x00"], 123, 2)
+    with pytest.raises(ValueError):
+        P.deserialize_array_threaded([b"\x00"], "{", 2)
+    with pytest.raises(NotImplementedError):
+        P.serialize_record_batch(None, SCHEMAS["flat4"], 1)
+    assert set(["deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
+                "serialize_record_batch", "serialize_record_batch_spawn"]) <= set(dir(P))   # src/lib.rs:150-158
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device failure mode")
+def test_no_device_fails_loudly_no_cpu_fallback():
+    with pytest.raises(RuntimeError) as ei:
+        P.deserialize_array([b"\x00\x00" + b"\x00" * 8 + b"\x00"], SCHEMAS["flat4"])
+    assert "no HIP device" in str(ei.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "pyruhvro_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle_walk" not in txt, f
