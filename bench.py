@@ -29,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+KERNEL = 0                      # rh_opts.flags: 0 auto, 1 generic interpreter, 2 schema-specialised
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     # name: (generator config, records per GPU, num_chunks, description)
@@ -47,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="full10m", choices=sorted(WORKLOADS))
     ap.add_argument("--records", type=int, default=0, help="override records per GPU (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     return ap.parse_args(argv)
 
@@ -113,6 +115,7 @@ def run(args, make_step=None, backend="nccl"):
     wall = time.perf_counter() - t0
     wall = rdist.max_over_ranks(wall, dev)
 
+    run.info = info
     local = {"records": n, "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
              "step_ms": wall * 1e3 / args.steps}
     for k in acc:
@@ -141,7 +144,7 @@ def gpu_step_factory(gen_cfg, n, row_lo, num_chunks, dev, local_rank):
 
     def step():
         r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
-                               device=local_rank, stream=stream)
+                               device=local_rank, stream=stream, kernel=KERNEL)
         info["output_bytes"] = r.output_bytes
         st = r.stats
         r.free()
@@ -150,11 +153,15 @@ def gpu_step_factory(gen_cfg, n, row_lo, num_chunks, dev, local_rank):
     step.keepalive = (d_data, d_off)
     first = step()      # also fills output_bytes
     assert first["records"] == n
+    info["specialized"] = int(first.get("specialized", 0))
+    info["lds_bytes"] = int(first.get("lds_bytes", 0))
     return step, info
 
 
 def main(argv=None):
     args = parse_args(argv)
+    global KERNEL
+    KERNEL = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
     import torch  # noqa: F401  (first: our library must share torch's HIP runtime)
     from avrogen.schemas import SCHEMAS
 
@@ -188,6 +195,8 @@ def main(argv=None):
                    "schema": gen_cfg, "input_bytes_per_gpu": int(b_in), "arrow_bytes_per_gpu": int(b_out),
                    "parallelism": f"{world} x independent shard (no data-path collective)",
                    "kernel_ms": {"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
+                   "kernel_form": "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter",
+                   "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
                    "path_kernel_ms": path_ms,
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": {"bound": "hbm", "kernel": "rh_k_emit", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

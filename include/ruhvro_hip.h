@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 1
+#define RH_ABI_VERSION 2
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -54,9 +54,17 @@ uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks);
 
 typedef struct {
   int32_t device;        /* HIP device ordinal; -1 = current device          */
-  int32_t flags;         /* reserved, 0                                      */
+  int32_t flags;         /* RH_KERNEL_* below; 0 = automatic                 */
   void* stream;          /* hipStream_t to launch on; NULL = engine's stream */
 } rh_opts;
+
+/* Kernel selection (rh_opts.flags).  Both forms are HIP kernels running the same field handlers and
+ * produce identical buffers; AUTO specialises the kernel to the schema when the call is large enough
+ * to amortise a one-off compile (RUHVRO_HIP_SPECIALIZE_MIN records, default 32768) or when the code
+ * object is already in the kernel cache, and uses the generic schema-program interpreter otherwise. */
+#define RH_KERNEL_AUTO 0
+#define RH_KERNEL_GENERIC 1
+#define RH_KERNEL_SPECIALIZED 2
 
 typedef struct {
   uint64_t records;
@@ -71,6 +79,8 @@ typedef struct {
   float emit_kernel_ms;      /* k_emit   (walk 2: column materialisation)        */
   float d2h_ms;
   float total_ms;
+  uint32_t specialized;      /* 1 = schema-specialised kernels ran, 0 = generic interpreter */
+  uint32_t lds_bytes;        /* dynamic LDS per workgroup of the emit kernel                 */
 } rh_stats;
 
 /* Replaces ruhvro::deserialize::per_datum_deserialize_threaded
@@ -109,6 +119,13 @@ int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDev
 /* Copy the chunks to host memory (same form rh_decode returns). */
 int rh_device_result_to_host(rh_device_result* r, struct ArrowArray* out_chunks, char** err);
 void rh_device_result_free(rh_device_result* r);
+
+/* Schema-specialised kernel management.  rh_schema_kernel_source returns the generated HIP source
+ * (malloc'd, release with rh_free_string).  rh_schema_prebuild generates, compiles (hiprtc, gfx950;
+ * needs no GPU) and stores the code object in the kernel cache so later processes only load it;
+ * returns 0 and sets *cached = 1 when it was already there. */
+char* rh_schema_kernel_source(const rh_schema* s);
+int rh_schema_prebuild(const rh_schema* s, int* cached, char** err);
 
 void rh_free_string(char* s);
 int rh_abi_version(void);

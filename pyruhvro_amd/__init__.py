@@ -78,6 +78,23 @@ def arrow_schema(schema: str) -> pa.Schema:
     return _get_schema(schema).arrow_schema
 
 
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+_kernel_mode = KERNEL_AUTO
+
+
+def set_kernel_mode(mode) -> int:
+    """Which HIP kernel form decodes: "auto" (default: schema-specialised kernels for large calls or when the
+    code object is cached, generic schema-program interpreter otherwise), "generic" or "specialized".
+    Both run on the GPU and produce identical buffers.  Returns the previous mode."""
+    global _kernel_mode
+    names = {"auto": KERNEL_AUTO, "generic": KERNEL_GENERIC, "specialized": KERNEL_SPECIALIZED}
+    new = names[mode] if isinstance(mode, str) else int(mode)
+    if new not in (0, 1, 2):
+        raise ValueError("kernel mode must be auto, generic or specialized")
+    old, _kernel_mode = _kernel_mode, new
+    return old
+
+
 def _decode(list_, schema: str, num_chunks: int, want_stats: bool = False, device: int = -1, stream: int = 0):
     comp = _get_schema(schema)
     nat = _require_native()
@@ -85,7 +102,7 @@ def _decode(list_, schema: str, num_chunks: int, want_stats: bool = False, devic
         raise TypeError("argument 'num_chunks': expected int")
     if num_chunks < 0:
         raise OverflowError("can't convert negative int to unsigned")  # usize extraction in PyO3
-    addrs, stats = nat.decode(comp.capsule, list_, num_chunks, device, stream, want_stats)
+    addrs, stats = nat.decode(comp.capsule, list_, num_chunks, device, stream, want_stats, _kernel_mode)
     out: List[pa.RecordBatch] = []
     try:
         for i, a in enumerate(addrs):
@@ -136,5 +153,5 @@ def device_count() -> int:
 
 __all__ = [
     "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
-    "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count",
+    "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count", "set_kernel_mode",
 ]

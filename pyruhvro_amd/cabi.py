@@ -27,7 +27,7 @@ class RhStats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64),
                 ("chunks", C.c_uint32), ("blocks", C.c_uint32), ("pack_ms", C.c_float), ("h2d_ms", C.c_float),
                 ("size_kernel_ms", C.c_float), ("scan_kernel_ms", C.c_float), ("emit_kernel_ms", C.c_float),
-                ("d2h_ms", C.c_float), ("total_ms", C.c_float)]
+                ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("specialized", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,6 +85,9 @@ def lib():
         L.rh_device_result_to_host.argtypes = [C.c_void_p, C.POINTER(ArrowArray), C.POINTER(C.c_char_p)]
         L.rh_device_result_free.argtypes = [C.c_void_p]
         L.rh_free_string.argtypes = [C.c_void_p]
+        L.rh_schema_kernel_source.restype = C.c_void_p
+        L.rh_schema_kernel_source.argtypes = [C.c_void_p]
+        L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_device_count.restype = C.c_int
         _lib = L
@@ -135,8 +138,35 @@ def _import_chunks(arr, k: int, schema: pa.Schema) -> List[pa.RecordBatch]:
     return [pa.RecordBatch._import_from_c(C.addressof(arr[i]), schema) for i in range(k)]
 
 
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+
+
+def kernel_source(schema_json: str) -> str:
+    """HIP source of the schema-specialised kernels (rh_schema_kernel_source)."""
+    L = lib()
+    p = L.rh_schema_kernel_source(Schema.get(schema_json).handle)
+    if not p:
+        raise RuntimeError("rh_schema_kernel_source failed")
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.rh_free_string(p)
+
+
+def prebuild(schema_json: str) -> bool:
+    """Compile the schema-specialised kernels into the on-disk kernel cache (hiprtc; no GPU needed).
+    Returns True when the code object was already cached."""
+    L = lib()
+    cached = C.c_int()
+    err = C.c_char_p()
+    rc = L.rh_schema_prebuild(Schema.get(schema_json).handle, C.byref(cached), C.byref(err))
+    if rc != RH_OK:
+        _raise(rc, err)
+    return bool(cached.value)
+
+
 def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_chunks: int,
-                  device: int = -1, want_stats: bool = False):
+                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO):
     """rh_decode_packed: one contiguous payload + u64 offsets (host memory) -> list[RecordBatch]."""
     L = lib()
     s = Schema.get(schema_json)
@@ -148,7 +178,7 @@ def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_c
     out_k = C.c_uint32()
     st = RhStats()
     err = C.c_char_p()
-    opts = RhOpts(device, 0, None)
+    opts = RhOpts(device, kernel, None)
     rc = L.rh_decode_packed(s.handle, data.ctypes.data, offsets.ctypes.data, n, num_chunks, C.byref(opts), arr,
                             C.byref(out_k), C.byref(st), C.byref(err))
     if rc != RH_OK:
@@ -195,14 +225,14 @@ class DeviceResult:
 
 
 def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
-                  device: int = -1, stream: int = 0, want_stats: bool = True) -> DeviceResult:
+                  device: int = -1, stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO) -> DeviceResult:
     """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr())."""
     L = lib()
     s = Schema.get(schema_json)
     out = C.c_void_p()
     st = RhStats()
     err = C.c_char_p()
-    opts = RhOpts(device, 0, stream or None)
+    opts = RhOpts(device, kernel, stream or None)
     rc = L.rh_decode_device(s.handle, d_data, d_offsets, data_len, n, num_chunks, C.byref(opts), C.byref(out),
                             C.byref(st) if want_stats else None, C.byref(err))
     if rc != RH_OK:

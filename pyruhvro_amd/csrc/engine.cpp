@@ -24,6 +24,7 @@
 #include "../../include/ruhvro_hip.h"
 #include "program.h"
 #include "schema.h"
+#include "specialize.h"
 
 extern "C" {
 int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream);
@@ -32,8 +33,9 @@ int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDe
                    void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream);
 int rh_set_max_lds(uint32_t bytes);
-uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes);
+uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
 }
+#include <memory>
 
 namespace {
 
@@ -168,6 +170,14 @@ struct DeviceProgram {
   uint32_t* sym_off = nullptr;
   uint8_t* sym_data = nullptr;
   rh::BufDesc* desc = nullptr;
+  int32_t* cnt_databuf = nullptr;
+};
+
+struct SpecKernel {      // schema-specialised k_size / k_emit loaded on one device
+  hipModule_t mod = nullptr;
+  hipFunction_t size_fn = nullptr, emit_fn = nullptr;
+  bool ok = false;
+  std::string why;
 };
 
 }  // namespace
@@ -176,6 +186,7 @@ struct rh_schema {
   std::unique_ptr<CompiledSchema> cs;
   std::mutex mu;
   std::map<int, DeviceProgram> dev;
+  std::map<int, SpecKernel> spec;
 };
 
 namespace {
@@ -196,7 +207,55 @@ const DeviceProgram& device_program(rh_schema* s, int device) {
   HIPCHK(hipMemcpy(d.sym_off, cs.sym_off.data(), so, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d.sym_data, cs.sym_data.data(), sd, hipMemcpyHostToDevice));
   if (!cs.bufs.empty()) HIPCHK(hipMemcpy(d.desc, cs.bufs.data(), cs.bufs.size() * sizeof(rh::BufDesc), hipMemcpyHostToDevice));
+  std::vector<int32_t> cdb((size_t)std::max(cs.K, 1), -1);
+  for (size_t b = 0; b < cs.bufs.size(); b++)
+    if (cs.bufs[b].kind == rh::BK_DATA) cdb[cs.bufs[b].counter] = (int32_t)b;
+  HIPCHK(hipMalloc((void**)&d.cnt_databuf, cdb.size() * 4));
+  HIPCHK(hipMemcpy(d.cnt_databuf, cdb.data(), cdb.size() * 4, hipMemcpyHostToDevice));
   return s->dev.emplace(device, d).first->second;
+}
+
+uint64_t spec_min_records() {
+  static const uint64_t v = [] {
+    const char* e = std::getenv("RUHVRO_HIP_SPECIALIZE_MIN");
+    return e ? (uint64_t)std::strtoull(e, nullptr, 10) : (uint64_t)32768;
+  }();
+  return v;
+}
+
+// Specialised kernels of this schema on `device`: code object from the kernel cache, or (allow_compile)
+// generated + compiled with hiprtc on the spot.  A failure is remembered (ok = false, why).
+const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile) {
+  std::lock_guard<std::mutex> g(s->mu);
+  auto it = s->spec.find(device);
+  if (it != s->spec.end() && (it->second.ok || !allow_compile || it->second.why != "not cached")) return it->second;
+  SpecKernel k;
+  try {
+    std::vector<char> image = rh::get_kernel_image(*s->cs, allow_compile, nullptr);
+    if (image.empty()) {
+      k.why = "not cached";
+    } else {
+      hipError_t e = hipModuleLoadData(&k.mod, image.data());
+      if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+      e = hipModuleGetFunction(&k.size_fn, k.mod, "rh_spec_size");
+      if (e == hipSuccess) e = hipModuleGetFunction(&k.emit_fn, k.mod, "rh_spec_emit");
+      if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.size_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.emit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      k.ok = true;
+    }
+  } catch (const std::exception& e) {
+    k.why = e.what();
+  }
+  s->spec[device] = k;
+  return s->spec[device];
+}
+
+int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t lds, hipStream_t stream) {
+  rh::KParams copy = P;
+  void* args[] = {&copy};
+  return (int)hipModuleLaunchKernel(f, grid, 1, 1, rh::kBlock, 1, 1, lds, stream, args, nullptr);
 }
 
 std::string format_error(const rh::ErrInfo& e) {
@@ -439,6 +498,16 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
 
   const DeviceProgram& dp = device_program(s, device);
 
+  // kernel form: schema-specialised (compiled once per schema, cached) or the generic interpreter
+  const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
+  const SpecKernel* sk = nullptr;
+  if (mode != RH_KERNEL_GENERIC && n > 0) {
+    const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
+    const SpecKernel& k0 = spec_kernel(s, device, may_compile);
+    if (k0.ok) sk = &k0;
+    else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
+  }
+
   // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
   const uint64_t o_null = 16;
   const uint64_t o_tot = align_up(o_null + 4ull * nnodes * k, 8);
@@ -457,6 +526,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   P.n = n; P.sz = r.sz; P.rows_last = r.rows_last; P.k = k; P.bpc = (uint32_t)bpc64; P.nblocks = nblocks;
   P.prog = dp.prog; P.sym_off = dp.sym_off; P.sym_data = dp.sym_data;
   P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
+  P.nbuf = nbuf; P.cnt_databuf = dp.cnt_databuf;
   P.first_bad = (unsigned long long*)ws.ptr();
   P.nullcount = (uint32_t*)(ws.ptr() + o_null);
   P.totals = (uint64_t*)(ws.ptr() + o_tot);
@@ -466,15 +536,15 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
 
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)
-  const uint32_t lds_fixed = rh_lds_fixed_bytes(K, cs.list_depth, nnodes);
+  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
   const uint64_t avg = n ? data_len / n + 1 : 16;
   uint64_t win = align_up(avg * rh::kBlock * 115 / 100 + 2048, 16);
   win = std::max<uint64_t>(win, 8192);
   const uint64_t lds_cap = 160 * 1024 - 512;
   if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
-  win = std::min<uint64_t>(win, std::min<uint64_t>(lds_cap - lds_fixed, 96 * 1024));
+  win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) * 5 / 9 & ~15ull, 80 * 1024));   // leave room for string staging
   P.win_bytes = (uint32_t)win;
-  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;
+  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;   // k_size; k_emit adds the string staging area
 
   Events ev;
   if (stats) ev.init();
@@ -492,7 +562,8 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   ev.rec(0, stream);
   std::vector<uint64_t> totals((size_t)K * k, 0);
   if (n > 0 && K > 0) {
-    if (rh_launch_size(&P, lds_bytes, stream)) throw HipError("k_size launch failed");
+    if (sk ? launch_module(sk->size_fn, P, nblocks, lds_bytes, stream) : rh_launch_size(&P, lds_bytes, stream))
+      throw HipError("k_size launch failed");
     ev.rec(1, stream);
     if (rh_launch_scan(&P, stream)) throw HipError("k_scan launch failed");
     ev.rec(2, stream);
@@ -546,15 +617,34 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   Lease dtab(dev_pool(), tab_bytes, device);
   void** hptr = (void**)htab.ptr();
   uint64_t* hsz = (uint64_t*)(htab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
-  for (size_t i = 0; i < (size_t)nbuf * k; i++) { hptr[i] = r.arena.ptr() + r.buf_off[i]; hsz[i] = r.buf_size[i]; }
+  for (uint32_t c = 0; c < k; c++)
+    for (int b = 0; b < nbuf; b++) {   // device tables are [chunk][buf]
+      hptr[(size_t)c * nbuf + b] = r.arena.ptr() + r.buf_off[(size_t)b * k + c];
+      hsz[(size_t)c * nbuf + b] = r.buf_size[(size_t)b * k + c];
+    }
   HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
   P.bufptr = (void* const*)dtab.ptr();
   const uint64_t* d_sizes = (const uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
 
   if (nbuf > 0 && rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, stream)) throw HipError("k_init launch failed");
   ev.rec(3, stream);
+  uint32_t emit_lds = 0;
   if (n > 0) {
-    if (rh_launch_emit(&P, lds_bytes, stream)) throw HipError("k_emit launch failed");
+    // string staging area: mean string bytes of 256 records + 25 %, one 16-byte phase slot per column
+    uint64_t str_total = 0;
+    int nstr = 0;
+    for (int kk = cs.ndom - 1; kk < K; kk++) {
+      nstr++;
+      for (uint32_t c = 0; c < k; c++) str_total += totals[(size_t)kk * k + c];
+    }
+    uint64_t stage = nstr ? align_up(str_total * rh::kBlock / n * 5 / 4 + 32ull * nstr + 1024, 16) : 0;
+    const uint64_t room = lds_cap > lds_bytes ? (lds_cap - lds_bytes) & ~15ull : 0;
+    if (stage > room) stage = room;
+    if (stage < 32ull * nstr + 256) stage = 0;
+    P.stage_bytes = (uint32_t)stage;
+    emit_lds = lds_bytes + (uint32_t)stage;
+    if (sk ? launch_module(sk->emit_fn, P, nblocks, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
+      throw HipError("k_emit launch failed");
   }
   ev.rec(4, stream);
   HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
@@ -572,6 +662,8 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
     stats->size_kernel_ms = ev.ms(0, 1);
     stats->scan_kernel_ms = ev.ms(1, 2);
     stats->emit_kernel_ms = ev.ms(3, 4);
+    stats->specialized = sk ? 1 : 0;
+    stats->lds_bytes = emit_lds;
   }
   return res.release();
 }
@@ -684,7 +776,10 @@ void rh_schema_free(rh_schema* s) {
     (void)hipFree(kv.second.sym_off);
     (void)hipFree(kv.second.sym_data);
     (void)hipFree(kv.second.desc);
+    (void)hipFree(kv.second.cnt_databuf);
   }
+  for (auto& kv : s->spec)
+    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   delete s;
 }
 
@@ -703,6 +798,26 @@ int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offse
     *out = decode_device_impl(const_cast<rh_schema*>(s), (const uint8_t*)d_data, (const uint64_t*)d_offsets, data_len,
                               n, num_chunks, opts, stats);
     if (stats) stats->total_ms = t.ms();
+    return RH_OK;
+  });
+}
+
+char* rh_schema_kernel_source(const rh_schema* s) {
+  if (!s) return nullptr;
+  try {
+    return dup_msg(rh::generate_kernel_source(*s->cs));
+  } catch (...) {
+    return nullptr;
+  }
+}
+
+int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
+  if (!s) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] {
+    bool hit = false;
+    std::vector<char> image = rh::get_kernel_image(*s->cs, true, &hit);
+    if (image.empty()) throw std::runtime_error("kernel image empty");
+    if (cached) *cached = hit ? 1 : 0;
     return RH_OK;
   });
 }

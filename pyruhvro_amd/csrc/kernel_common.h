@@ -1,0 +1,91 @@
+// Workgroup-level pieces shared by the generic interpreter kernels (kernels.hip)
+// and the per-schema specialised kernels (spec_body.h): chunk / workgroup
+// geometry, the coalesced global -> LDS window load, lane set-up, error
+// reporting and the aligned flush of staged string bytes.
+#pragma once
+#include "program.h"
+#include "walk.h"
+
+namespace rh {
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// One workgroup = 256 consecutive records of ONE output chunk (chunk boundaries of
+// ruhvro/src/deserialize.rs:57-68: k-1 chunks of sz rows, the last one takes the remainder).
+struct Geo {
+  uint32_t chunk;
+  uint32_t lrow0;     // chunk-local row of lane 0 of the workgroup
+  uint64_t rec0;      // global record index of lane 0
+  uint32_t nrec;      // live rows in this workgroup (1..256)
+};
+
+__device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
+  Geo g;
+  uint32_t chunk = b / P.bpc;
+  if (chunk > P.k - 1) chunk = P.k - 1;
+  const uint32_t lb = b - chunk * P.bpc;
+  const uint64_t rows_c = chunk == P.k - 1 ? P.rows_last : P.sz;
+  g.chunk = chunk;
+  g.lrow0 = lb * kBlock;
+  g.rec0 = (uint64_t)chunk * P.sz + g.lrow0;
+  const uint64_t left = rows_c - g.lrow0;
+  g.nrec = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
+  return g;
+}
+
+// Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction).
+__device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uint64_t wb16, uint64_t we, uint32_t tid) {
+  const uint32_t nvec = (uint32_t)((we - wb16 + 15) >> 4);
+  const uint8_t* g = P.data + wb16;
+  for (uint32_t i = tid; i < nvec; i += kBlock) {
+    const uint64_t pos = wb16 + ((uint64_t)i << 4);
+    if (pos + 16 <= P.data_len) {
+      reinterpret_cast<v4u*>(win)[i] = *reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(g + ((size_t)i << 4)));
+    } else {
+      for (uint32_t j = 0; j < 16; j++) win[(i << 4) + j] = pos + j < P.data_len ? g[((size_t)i << 4) + j] : 0;
+    }
+  }
+}
+
+__device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& g, uint64_t wb16, uint32_t tid) {
+  L.live = tid < g.nrec;
+  L.pres = L.live;
+  L.err = 0;
+  L.edetail = 0;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0;
+  L.cur = 0; L.end = 0;
+  if (L.live) {
+    const uint64_t o0 = P.offsets[g.rec0 + tid], o1 = P.offsets[g.rec0 + tid + 1];
+    L.cur = (uint32_t)(o0 - wb16);
+    L.end = (uint32_t)(o1 - wb16);
+  }
+}
+
+// Lowest erroring lane of the workgroup reports (code, detail); lowest record index wins globally
+// (== the in-order join of deserialize.rs:115-119 + first `?` in fast_decode.rs:827).
+// Contains a workgroup barrier.
+__device__ __forceinline__ void report_errors(const KParams& P, uint32_t* misc, const Lane& L, const Geo& g, uint32_t tid) {
+  if (L.err) atomicMin(&misc[0], tid);
+  __syncthreads();
+  if (misc[0] == tid) {
+    ErrInfo ei; ei.code = L.err; ei.pad = 0; ei.detail = L.edetail;
+    P.errinfo[blockIdx.x] = ei;
+    atomicMax(P.first_bad, ~(unsigned long long)(g.rec0 + tid));
+  }
+}
+
+// One wave copies T staged bytes (LDS, same 16-byte phase as the destination) to HBM address `ga`:
+// <= 15 head bytes, aligned 16-byte vectors (1 KiB per instruction), <= 15 tail bytes.
+__device__ __forceinline__ void flush_column(uint64_t ga, const uint8_t* sp, uint32_t T, uint32_t lane) {
+  RH_GLOBAL uint8_t* gp = reinterpret_cast<RH_GLOBAL uint8_t*>(ga);
+  uint32_t head = (16u - (uint32_t)(ga & 15)) & 15u;
+  if (head > T) head = T;
+  if (lane < head) gp[lane] = sp[lane];
+  const uint32_t body = T - head, nvec = body >> 4, tail = body & 15;
+  RH_GLOBAL v4u* gv = reinterpret_cast<RH_GLOBAL v4u*>(ga + head);
+  const v4u* sv = reinterpret_cast<const v4u*>(sp + head);
+  for (uint32_t i = lane; i < nvec; i += 64) gv[i] = sv[i];
+  if (lane < tail) gp[head + (nvec << 4) + lane] = sp[head + (nvec << 4) + lane];
+}
+
+}  // namespace rh

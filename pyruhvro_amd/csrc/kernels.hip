@@ -1,24 +1,10 @@
-// CDNA4 (gfx950) kernels of the Avro -> Arrow direct-decode path.
+// CDNA4 (gfx950) kernels of the Avro -> Arrow direct-decode path: the generic
+// (any supported schema) form, driven by the schema program of program.h.
 //
 // One workgroup = 256 consecutive records of one output chunk, one lane per
-// record (the per-record unit of work of the reference's hot loop,
-// ruhvro/src/fast_decode.rs:825-828).  The workgroup's input bytes are one
-// contiguous window of the packed payload, staged into LDS with 16-byte
-// coalesced loads; every lane then walks its own record out of LDS.
-//
-// The walker is a WAVE-UNIFORM interpreter of the schema program
-// (program.h): the program counter is scalar, all 64 lanes execute the same
-// op, and the reference's data-dependent control flow becomes per-lane
-// predicates:
-//   * live  -- the lane owns a row in the current row domain,
-//   * pres  -- the row is decoded from bytes (true) or null-filled (false),
-//              i.e. FieldDecoder::decode vs FieldDecoder::append_null
-//              (fast_decode.rs:421-499 vs 503-534).
-// Nullable records and N-variant unions only flip `pres` (children of a null
-// record / non-selected variants are visited in null-fill mode, exactly the
-// sparse-union / null-struct fill of fast_decode.rs:608-616,649-655); array
-// and map blocks run as a wave loop that lasts as long as any lane still has
-// items (ballot), lanes without an item are simply not live.
+// record.  The workgroup's input bytes are one contiguous window of the packed
+// payload, staged into LDS with 16-byte coalesced loads; every lane then walks
+// its own record out of LDS with unaligned 8-byte DS reads (walk.h).
 //
 // Kernels:
 //   k_size  walk 1: per-record counters (child rows per array/map domain,
@@ -31,436 +17,146 @@
 //   k_emit  recomputes the counters of its 256 records, scans them inside the
 //           workgroup, then walk 2 writes every Arrow buffer: values and
 //           offsets at [row] (coalesced), validity / boolean bitmaps with one
-//           64-bit ballot store per wavefront, string bytes at the scanned
-//           byte offsets, sparse-union type ids.
+//           64-bit ballot store per wavefront, sparse-union type ids.  String
+//           bytes are gathered per column into an LDS staging area laid out
+//           with the destination's 16-byte phase, and flushed to HBM with
+//           aligned 16-byte stores (one wave per column, 1 KiB per
+//           instruction) -- no per-lane byte stores to HBM.
 // HBM-bound byte shuffling: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "kernel_common.h"
 #include "program.h"
+#include "walk.h"
 
 namespace rh {
 
 // --------------------------------------------------------------------------
-// wave / block primitives (wave = 64 lanes)
+// interpreter context: per-lane counters live in LDS ([id][256], conflict-free)
 // --------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= (uint32_t)d) v += t;
-  }
-  return v;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-
-// --------------------------------------------------------------------------
-// per-lane walker state
-// --------------------------------------------------------------------------
-struct Lane {
-  uint32_t cur, end;   // byte cursor / record end, relative to the window base
-  uint32_t err;        // ErrCode, 0 = ok
-  int64_t edetail;
-  bool live, pres;
-  uint32_t pstk;       // saved `pres` bits   (nullable record / union / list)
-  uint32_t lstk;       // saved `live` bits   (list)
-  uint64_t sstk;       // saved union selectors, 8 bits each
-};
-
-struct Ctx {
-  const KParams* P;
-  uint32_t* cnt;       // LDS [K][256]   running child row / byte offset per counter
-  uint32_t* rem;       // LDS [depth][256] items left in the current block
-  uint32_t* nullcnt;   // LDS [nnodes]
-  uint32_t chunk;
-  uint32_t lrow;       // chunk-local row of this lane (domain 0)
+struct ICtx {
+  uint32_t* cnt;             // LDS [K][256]
+  uint32_t* rem;             // LDS [depth][256]
+  uint32_t* nullcnt;         // LDS [nnodes]
+  const uint64_t* bufs;      // LDS [nbuf]   this chunk's buffer addresses
+  const uint32_t* gb;        // LDS [K]      chunk-relative base of this workgroup per counter
+  const uint32_t* so;        // LDS [K]      staging offset per string counter
+  uint8_t* stg;              // LDS staging area
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  uint32_t lrow;             // chunk-local row of this lane (domain 0)
   uint32_t tid, lane;
-  bool wave_live;      // the wave owns at least one row (uniform)
+  bool wave_live;            // the wave owns at least one row (uniform)
+
+  __device__ __forceinline__ uint32_t& counter(int id) const { return cnt[id * kBlock + tid]; }
+  __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d * kBlock + tid]; }
+  __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
+  __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
+  __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
+  __device__ __forceinline__ uint8_t* stage() const { return stg; }
+  __device__ __forceinline__ void add_nulls(int node, uint32_t n) const { atomicAdd(&nullcnt[node], n); }
 };
 
-// zig-zag LEB128 varint, fast_decode.rs:854-869
-template <typename SrcT>
-__device__ __forceinline__ uint32_t rd_varint(SrcT src, uint32_t& cur, uint32_t end, int64_t& out) {
-  uint64_t r = 0;
-  uint32_t shift = 0;
-  for (;;) {
-    if (cur >= end) return E_EOB;
-    uint32_t b = src[cur++];
-    r |= (uint64_t)(b & 0x7F) << shift;
-    if ((b & 0x80) == 0) break;
-    shift += 7;
-    if (shift >= 64) return E_VARINT;
-  }
-  out = (int64_t)(r >> 1) ^ -(int64_t)(r & 1);
-  return E_OK;
-}
-
-// union_branch, fast_decode.rs:585-593.  Returns true for the value branch.
-template <typename SrcT>
-__device__ __forceinline__ bool rd_branch(SrcT src, Lane& L, bool null_first) {
-  int64_t idx = 0;
-  uint32_t e = rd_varint(src, L.cur, L.end, idx);
-  if (e) { L.err = e; return false; }
-  if (idx == 0) return !null_first;
-  if (idx == 1) return null_first;
-  L.err = E_BRANCH;
-  L.edetail = idx;
-  return false;
-}
-
-__device__ __forceinline__ void* bufp(const Ctx& c, int32_t id) {
-  return c.P->bufptr[(size_t)id * c.P->k + c.chunk];
-}
-
-__device__ __forceinline__ uint32_t row_of(const Ctx& c, const Op& op) {
-  return op.dom == 0 ? c.lrow : c.cnt[(op.dom - 1) * kBlock + c.tid];
-}
-
-// validity bit + null count of one row (buffer exists iff F_CAN_NULL)
-template <bool EMIT>
-__device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool act, bool valid, uint32_t row) {
-  if (!EMIT) return;
-  if (!(op.flags & F_CAN_NULL)) return;
-  if (op.dom == 0) {
-    uint64_t m = __ballot(valid);
-    uint64_t nm = __ballot(act && !valid);
-    if (c.lane == 0 && c.wave_live) {
-      reinterpret_cast<uint64_t*>(bufp(c, op.buf0))[c.lrow >> 6] = m;
-      if (nm) atomicAdd(&c.nullcnt[op.node], (uint32_t)__popcll(nm));
-    }
-  } else if (act) {
-    if (valid) atomicOr(&reinterpret_cast<uint32_t*>(bufp(c, op.buf0))[row >> 5], 1u << (row & 31));
-    else atomicAdd(&c.nullcnt[op.node], 1u);
-  }
-}
-
 // --------------------------------------------------------------------------
-// the interpreter
+// the interpreter: scalar program counter, one handler call per op
 // --------------------------------------------------------------------------
-template <bool EMIT, typename SrcT>
-__device__ __forceinline__ void walk(const Ctx& c, SrcT src, Lane& L) {
-  const KParams& P = *c.P;
+template <bool EMIT, class Src>
+__device__ __forceinline__ void walk(const KParams& P, const ICtx& c, const Src& src, Lane& L) {
   int pc = 0;
   for (;;) {
     pc = __builtin_amdgcn_readfirstlane(pc);
     const Op op = P.prog[pc];
-    const bool act = L.live && L.err == 0;
     switch (op.code) {
-      case OP_END:
-        return;
-
-      case OP_FIXED: {
-        const bool dec = act && L.pres;
-        bool isval = dec;
-        if ((op.flags & F_NULLABLE) && dec) isval = rd_branch(src, L, op.flags & F_NULL_FIRST);
-        uint64_t bits = 0;
-        if (dec && isval && L.err == 0) {
-          if (op.a == FK_I32 || op.a == FK_I64) {
-            int64_t v = 0;
-            uint32_t e = rd_varint(src, L.cur, L.end, v);
-            if (e) L.err = e;
-            bits = op.a == FK_I32 ? (uint64_t)(uint32_t)(int32_t)v : (uint64_t)v;   // `as i32` truncates
-          } else if (op.a == FK_F32) {
-            if (L.end - L.cur < 4) L.err = E_EOB_F32;
-            else {
-              for (int j = 0; j < 4; j++) bits |= (uint64_t)src[L.cur + j] << (8 * j);
-              L.cur += 4;
-            }
-          } else if (op.a == FK_F64) {
-            if (L.end - L.cur < 8) L.err = E_EOB_F64;
-            else {
-              for (int j = 0; j < 8; j++) bits |= (uint64_t)src[L.cur + j] << (8 * j);
-              L.cur += 8;
-            }
-          } else {  // FK_BOOL, fast_decode.rs:893-900
-            if (L.cur >= L.end) L.err = E_EOB;
-            else {
-              uint32_t b = src[L.cur++];
-              if (b > 1) { L.err = E_BOOL; L.edetail = b; }
-              bits = b;
-            }
-          }
-        }
-        const bool valid = dec && isval && L.err == 0;
-        if (!valid) bits = 0;   // zero under nulls (arrow-rs append_null)
-        uint32_t row = 0;
-        if (EMIT) {
-          row = row_of(c, op);
-          if (op.a == FK_BOOL) {
-            if (op.dom == 0) {
-              uint64_t m = __ballot(bits != 0);
-              if (c.lane == 0 && c.wave_live) reinterpret_cast<uint64_t*>(bufp(c, op.buf1))[c.lrow >> 6] = m;
-            } else if (act && bits) {
-              atomicOr(&reinterpret_cast<uint32_t*>(bufp(c, op.buf1))[row >> 5], 1u << (row & 31));
-            }
-          } else if (act) {
-            if (op.a == FK_I32 || op.a == FK_F32) reinterpret_cast<uint32_t*>(bufp(c, op.buf1))[row] = (uint32_t)bits;
-            else reinterpret_cast<uint64_t*>(bufp(c, op.buf1))[row] = bits;
-          }
-        }
-        put_validity<EMIT>(c, op, act, valid, row);
-        break;
-      }
-
+      case OP_END: return;
+      case OP_FIXED: h_fixed<EMIT>(c, src, L, op); break;
       case OP_STRING:
-      case OP_ENUM: {
-        const bool dec = act && L.pres;
-        bool isval = dec;
-        if ((op.flags & F_NULLABLE) && dec) isval = rd_branch(src, L, op.flags & F_NULL_FIRST);
-        uint32_t len = 0, spos = 0;
-        if (dec && isval && L.err == 0) {
-          int64_t v = 0;
-          uint32_t e = rd_varint(src, L.cur, L.end, v);
-          if (e) L.err = e;
-          else if (op.code == OP_STRING) {          // read_string, fast_decode.rs:902-922
-            if (v < 0) L.err = E_NEGLEN;
-            else if ((uint64_t)(L.end - L.cur) < (uint64_t)v) L.err = E_EOB_STR;
-            else { len = (uint32_t)v; spos = L.cur; L.cur += len; }
-          } else {                                  // append_enum, fast_decode.rs:570-578
-            if ((uint64_t)v >= (uint64_t)op.c) { L.err = E_ENUM; L.edetail = v; }
-            else {
-              spos = P.sym_off[op.b + (int32_t)v];
-              len = P.sym_off[op.b + (int32_t)v + 1] - spos;
-            }
-          }
-        }
-        const bool valid = dec && isval && L.err == 0;
-        if (!valid) len = 0;
-        uint32_t* bo = &c.cnt[op.a * kBlock + c.tid];
-        const uint32_t o = *bo;
-        uint32_t row = 0;
-        if (EMIT) {
-          row = row_of(c, op);
-          if (act) {
-            reinterpret_cast<uint32_t*>(bufp(c, op.buf1))[row + 1] = o + len;   // offsets repeat under nulls
-            if (len) {
-              uint8_t* d = reinterpret_cast<uint8_t*>(bufp(c, op.buf2)) + o;
-              if (op.code == OP_STRING) {
-                for (uint32_t j = 0; j < len; j++) d[j] = src[spos + j];
-              } else {
-                for (uint32_t j = 0; j < len; j++) d[j] = P.sym_data[spos + j];
-              }
-            }
-          }
-        }
-        if (act) *bo = o + len;
-        put_validity<EMIT>(c, op, act, valid, row);
+      case OP_ENUM: h_string<EMIT>(c, src, L, op); break;
+      case OP_REC_BEGIN: h_rec_begin<EMIT>(c, src, L, op); break;
+      case OP_REC_END: h_rec_end(L); break;
+      case OP_UNION_BEGIN: h_union_begin<EMIT>(c, src, L, op); break;
+      case OP_VARIANT: h_variant(L, op); break;
+      case OP_UNION_END: h_union_end(L); break;
+      case OP_LIST_BEGIN: h_list_begin<EMIT>(c, src, L, op); break;
+      case OP_LIST_NEXT:
+        if (!h_list_next(c, src, L, op)) { pc = op.b; continue; }
         break;
-      }
-
-      case OP_REC_BEGIN: {   // NullableRecord, fast_decode.rs:482-485 + 595-616
-        L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
-        const bool dec = act && L.pres;
-        bool isval = dec;
-        if (dec) isval = rd_branch(src, L, op.flags & F_NULL_FIRST);
-        const bool valid = dec && isval && L.err == 0;
-        put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op) : 0);
-        L.pres = valid;      // null record -> children are null-filled
-        break;
-      }
-      case OP_REC_END:
-        L.pres = L.pstk & 1;
-        L.pstk >>= 1;
-        break;
-
-      case OP_UNION_BEGIN: {   // UnionDecoder::decode / append_null, fast_decode.rs:643-668
-        L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
-        L.sstk = (L.sstk << 8) | 0xFFull;
-        const bool dec = act && L.pres;
-        uint32_t tidv = 0;
-        if (dec) {
-          int64_t idx = 0;
-          uint32_t e = rd_varint(src, L.cur, L.end, idx);
-          if (e) L.err = e;
-          else if (idx < 0 || idx >= (int64_t)op.a) { L.err = E_UNION; L.edetail = idx; }
-          else { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
-        }
-        if (EMIT && act) reinterpret_cast<int8_t*>(bufp(c, op.buf1))[row_of(c, op)] = (int8_t)tidv;
-        break;
-      }
-      case OP_VARIANT:
-        L.pres = (L.pstk & 1) && ((uint32_t)(L.sstk & 0xFF) == (uint32_t)op.a);
-        break;
-      case OP_UNION_END:
-        L.pres = L.pstk & 1;
-        L.pstk >>= 1;
-        L.sstk >>= 8;
-        break;
-
-      case OP_LIST_BEGIN: {   // ListDecoder / MapDecoder (+ Nullable*), fast_decode.rs:487-496,703-770
-        L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
-        L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
-        const bool dec = act && L.pres;
-        bool isval = dec;
-        if ((op.flags & F_NULLABLE) && dec) isval = rd_branch(src, L, op.flags & F_NULL_FIRST);
-        const bool valid = dec && isval && L.err == 0;
-        put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op) : 0);
-        L.live = valid;      // only rows that really carry a list enter the block loop
-        L.pres = valid;
-        c.rem[op.c * kBlock + c.tid] = 0;
-        break;
-      }
-      case OP_LIST_NEXT: {    // read_block_count, fast_decode.rs:689-700
-        uint32_t* rm = &c.rem[op.c * kBlock + c.tid];
-        if (act && *rm == 0) {
-          for (;;) {
-            int64_t n = 0;
-            uint32_t e = rd_varint(src, L.cur, L.end, n);
-            if (e) { L.err = e; break; }
-            if (n < 0) {
-              int64_t bsz;
-              e = rd_varint(src, L.cur, L.end, bsz);   // block byte size, ignored
-              if (e) { L.err = e; break; }
-              n = (int64_t)(0 - (uint64_t)n);
-            }
-            if (n == 0) { L.live = false; break; }
-            if (n < 0) continue;                         // i64::MIN negates to itself: `0..n` is empty
-            // Clamp the trip count: with m = min wire bytes per item and R bytes left, no more
-            // than R/m items can decode, so item R/m+1 raises the same error the reference hits.
-            const uint64_t R = L.end - L.cur;
-            if (op.buf2 /*min wire bytes per item*/ > 0) {
-              uint64_t cap = R / (uint32_t)op.buf2 + 1;
-              *rm = (uint32_t)((uint64_t)n < cap ? (uint64_t)n : cap);
-            } else if ((uint64_t)n > 0x00FFFFFFull) {
-              L.err = E_LIST_RANGE; L.edetail = n;
-            } else {
-              *rm = (uint32_t)n;
-            }
-            break;
-          }
-        }
-        const bool item = L.live && L.err == 0;
-        if (!__any(item)) { pc = op.b; continue; }
-        L.pres = L.live;
-        break;
-      }
-      case OP_LIST_TAIL: {
-        if (act) {
-          c.rem[op.c * kBlock + c.tid] -= 1;
-          c.cnt[(op.a - 1) * kBlock + c.tid] += 1;     // op.a = child row domain
-        }
+      case OP_LIST_TAIL:
+        h_list_tail(c, L, op);
         pc = op.b;
         continue;
-      }
-      case OP_LIST_END: {
-        L.live = L.lstk & 1;
-        L.lstk >>= 1;
-        L.pres = L.pstk & 1;
-        L.pstk >>= 1;
-        if (EMIT && L.live && L.err == 0) {
-          // cumulative child rows so far == Arrow offset of the next row (null / empty rows repeat it)
-          reinterpret_cast<uint32_t*>(bufp(c, op.buf1))[row_of(c, op) + 1] = c.cnt[(op.a - 1) * kBlock + c.tid];
-        }
-        break;
-      }
-      default:
-        return;
+      case OP_LIST_END: h_list_end<EMIT>(c, L, op); break;
+      default: return;
     }
     pc++;
   }
 }
 
 // --------------------------------------------------------------------------
-// workgroup geometry + LDS carving shared by k_size / k_emit
+// LDS carving shared by k_size / k_emit
 // --------------------------------------------------------------------------
-struct Geo {
-  uint32_t chunk;
-  uint32_t lrow0;     // chunk-local row of lane 0 of the workgroup
-  uint64_t rec0;      // global record index of lane 0
-  uint32_t nrec;      // live rows in this workgroup (1..256)
-};
-
-__device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
-  Geo g;
-  uint32_t chunk = b / P.bpc;
-  if (chunk > P.k - 1) chunk = P.k - 1;
-  const uint32_t lb = b - chunk * P.bpc;
-  const uint64_t rows_c = chunk == P.k - 1 ? P.rows_last : P.sz;
-  g.chunk = chunk;
-  g.lrow0 = lb * kBlock;
-  g.rec0 = (uint64_t)chunk * P.sz + g.lrow0;
-  const uint64_t left = rows_c - g.lrow0;
-  g.nrec = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
-  return g;
-}
-
 struct Smem {
   uint32_t* cnt;      // [K][256]
   uint32_t* rem;      // [list_depth][256]
-  uint32_t* nullcnt;  // [nnodes]
   uint32_t* wtot;     // [K][4]
+  uint32_t* tot;      // [K]   workgroup totals
+  uint32_t* gb;       // [K]   chunk-relative workgroup base
+  uint32_t* so;       // [K]   staging offsets
+  uint32_t* nullcnt;  // [nnodes]
   uint32_t* misc;     // [4]: 0 = lowest erroring tid
-  uint8_t* win;       // input window (16-byte aligned)
+  uint64_t* bufs;     // [nbuf]
+  uint8_t* win;       // input window (16-byte aligned, +16 bytes of slack)
+  uint8_t* stage;     // string staging (16-byte aligned)
 };
+
+__host__ __device__ inline uint32_t lds_fixed_words(int K, int list_depth, int nnodes, int nbuf) {
+  const uint32_t k1 = (uint32_t)(K > 0 ? K : 1);
+  const uint32_t k4 = (k1 + 3) & ~3u;
+  return k1 * kBlock + (uint32_t)(list_depth > 0 ? list_depth : 1) * kBlock + k1 * 4 + 3 * k4 +
+         (uint32_t)((nnodes + 3) & ~3) + 4 + 2 * (uint32_t)((nbuf + 1) & ~1);
+}
 
 __device__ __forceinline__ Smem carve(const KParams& P, uint8_t* smem) {
   Smem s;
+  const uint32_t k1 = (uint32_t)(P.K > 0 ? P.K : 1);
+  const uint32_t k4 = (k1 + 3) & ~3u;
   uint32_t* p = reinterpret_cast<uint32_t*>(smem);
-  s.cnt = p; p += (P.K > 0 ? P.K : 1) * kBlock;
+  s.cnt = p; p += k1 * kBlock;
   s.rem = p; p += (P.list_depth > 0 ? P.list_depth : 1) * kBlock;
-  s.wtot = p; p += (P.K > 0 ? P.K : 1) * 4;
+  s.wtot = p; p += k1 * 4;
+  s.tot = p; p += k4;
+  s.gb = p; p += k4;
+  s.so = p; p += k4;
   s.nullcnt = p; p += ((P.nnodes + 3) & ~3);
   s.misc = p; p += 4;
-  s.win = reinterpret_cast<uint8_t*>(p);   // all pieces above are multiples of 16 bytes
+  s.bufs = reinterpret_cast<uint64_t*>(p); p += 2 * ((P.nbuf + 1) & ~1);
+  s.win = reinterpret_cast<uint8_t*>(p);          // all pieces above are multiples of 16 bytes
+  s.stage = s.win + P.win_bytes + 16;
   return s;
 }
 
 // Host mirror of carve(): LDS bytes in front of the window.
-extern "C" uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes) {
-  uint32_t w = (uint32_t)(K > 0 ? K : 1) * kBlock + (uint32_t)(list_depth > 0 ? list_depth : 1) * kBlock +
-               (uint32_t)(K > 0 ? K : 1) * 4 + (uint32_t)((nnodes + 3) & ~3) + 4;
-  return w * 4;
-}
-
-// Stage [wb16, we) of the payload into LDS with 16-byte loads.
-__device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uint64_t wb16, uint64_t we, uint32_t tid) {
-  const uint32_t nvec = (uint32_t)((we - wb16 + 15) >> 4);
-  const uint8_t* g = P.data + wb16;
-  for (uint32_t i = tid; i < nvec; i += kBlock) {
-    const uint64_t pos = wb16 + ((uint64_t)i << 4);
-    if (pos + 16 <= P.data_len) {
-      reinterpret_cast<uint4*>(win)[i] = *reinterpret_cast<const uint4*>(g + ((size_t)i << 4));
-    } else {
-      for (uint32_t j = 0; j < 16; j++) win[(i << 4) + j] = pos + j < P.data_len ? g[((size_t)i << 4) + j] : 0;
-    }
-  }
-}
-
-__device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& g, uint64_t wb16, uint32_t tid) {
-  L.live = tid < g.nrec;
-  L.pres = L.live;
-  L.err = 0;
-  L.edetail = 0;
-  L.pstk = 0; L.lstk = 0; L.sstk = 0;
-  L.cur = 0; L.end = 0;
-  if (L.live) {
-    const uint64_t o0 = P.offsets[g.rec0 + tid], o1 = P.offsets[g.rec0 + tid + 1];
-    L.cur = (uint32_t)(o0 - wb16);
-    L.end = (uint32_t)(o1 - wb16);
-  }
-}
-
-// Lowest erroring lane of the workgroup reports (code, detail); lowest record index wins globally
-// (== the in-order join of deserialize.rs:115-119 + first `?` in fast_decode.rs:827).
-__device__ __forceinline__ void report_errors(const KParams& P, const Smem& s, const Lane& L, const Geo& g, uint32_t tid) {
-  if (L.err) atomicMin(&s.misc[0], tid);
-  __syncthreads();
-  if (s.misc[0] == tid) {
-    ErrInfo ei; ei.code = L.err; ei.pad = 0; ei.detail = L.edetail;
-    P.errinfo[blockIdx.x] = ei;
-    atomicMax(P.first_bad, ~(unsigned long long)(g.rec0 + tid));
-  }
+extern "C" uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf) {
+  return lds_fixed_words(K, list_depth, nnodes, nbuf) * 4;
 }
 
 template <bool EMIT>
-__device__ __forceinline__ void run_walk(const Ctx& c, const Smem& s, Lane& L, bool fits, uint64_t wb16) {
-  if (fits) walk<EMIT, const uint8_t*>(c, s.win, L);
-  else walk<EMIT, const uint8_t*>(c, c.P->data + wb16, L);
+__device__ __forceinline__ void run_walk(const KParams& P, const ICtx& c, const Smem& s, Lane& L, bool fits, uint64_t wb16) {
+  if (fits) {
+    LdsSrc src{s.win};
+    walk<EMIT>(P, c, src, L);
+  } else {
+    GlobalSrc src{P.data + wb16, P.data_len - wb16};
+    walk<EMIT>(P, c, src, L);
+  }
+}
+
+__device__ __forceinline__ ICtx make_ctx(const KParams& P, const Smem& s, const Geo& g, uint32_t tid) {
+  ICtx c;
+  c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.bufs = s.bufs; c.gb = s.gb; c.so = s.so; c.stg = s.stage;
+  c.sym_off = P.sym_off; c.sym_data = P.sym_data;
+  c.lrow = g.lrow0 + tid; c.tid = tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
+  return c;
 }
 
 // --------------------------------------------------------------------------
@@ -481,17 +177,15 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) {
 
   Lane L;
   lane_init(L, P, g, wb16, tid);
-  if (L.live && (we - wb16) > 0xFFFFFFF0ull) { L.err = E_EOB; L.live = true; }   // window beyond 32-bit cursors
-  Ctx c;
-  c.P = &P; c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.chunk = g.chunk;
-  c.lrow = g.lrow0 + tid; c.tid = tid; c.lane = lane; c.wave_live = (wave * 64) < g.nrec;
-  run_walk<false>(c, s, L, fits, wb16);
+  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
+  const ICtx c = make_ctx(P, s, g, tid);
+  run_walk<false>(P, c, s, L, fits, wb16);
 
   for (int k = 0; k < P.K; k++) {
     uint32_t v = wave_sum(s.cnt[k * kBlock + tid]);
     if (lane == 0) s.wtot[k * 4 + wave] = v;
   }
-  report_errors(P, s, L, g, tid);   // contains the barrier that publishes wtot
+  report_errors(P, s.misc, L, g, tid);   // contains the barrier that publishes wtot
   if ((int)tid < P.K)
     P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
@@ -527,11 +221,11 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {
 
 // --------------------------------------------------------------------------
 // k_init: offsets[0] = 0 for every offsets buffer, zero the atomically-built bitmaps.
-// grid = nbuf * k workgroups; desc/sizes live next to bufptr.
+// grid = k * nbuf workgroups ([chunk][buf] tables)
 // --------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_init(void* const* bufptr, const uint64_t* bufsize,
                                                               const BufDesc* desc, uint32_t nbuf, uint32_t k) {
-  const uint32_t id = blockIdx.x / k;
+  const uint32_t id = blockIdx.x % nbuf;
   const BufDesc d = desc[id];
   uint8_t* p = reinterpret_cast<uint8_t*>(bufptr[blockIdx.x]);
   const uint64_t sz = bufsize[blockIdx.x];
@@ -556,18 +250,18 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   if (fits) stage_window(P, s.win, wb16, we, tid);
   for (int k = 0; k < P.K; k++) s.cnt[k * kBlock + tid] = 0;
   for (int i = tid; i < P.nnodes; i += kBlock) s.nullcnt[i] = 0;
+  for (int i = tid; i < P.nbuf; i += kBlock)
+    s.bufs[i] = reinterpret_cast<uint64_t>(P.bufptr[(size_t)g.chunk * P.nbuf + i]);
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
 
   Lane L;
-  Ctx c;
-  c.P = &P; c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.chunk = g.chunk;
-  c.lrow = g.lrow0 + tid; c.tid = tid; c.lane = lane; c.wave_live = (wave * 64) < g.nrec;
+  const ICtx c = make_ctx(P, s, g, tid);
 
   if (P.K > 0) {
     // walk 1 again (cheaper than 4*K bytes/record of HBM round trip), then the in-workgroup scan
     lane_init(L, P, g, wb16, tid);
-    run_walk<false>(c, s, L, fits, wb16);
+    run_walk<false>(P, c, s, L, fits, wb16);
     for (int k = 0; k < P.K; k++) {
       const uint32_t v = s.cnt[k * kBlock + tid];
       const uint32_t incl = wave_incl_scan(v, lane);
@@ -576,20 +270,50 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
     }
     __syncthreads();
     for (int k = 0; k < P.K; k++) {
-      uint32_t base = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
+      uint32_t base = 0;
       for (uint32_t w = 0; w < wave; w++) base += s.wtot[k * 4 + w];
-      s.cnt[k * kBlock + tid] += base;
+      s.cnt[k * kBlock + tid] += base;             // workgroup-local exclusive prefix
     }
+    if ((int)tid < P.K) {
+      s.tot[tid] = s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
+      s.gb[tid] = P.blockbase[(size_t)tid * P.nblocks + blockIdx.x];
+    }
+    __syncthreads();
+    // staging layout: column k's bytes start at stage + so[k], with so[k] == HBM destination (mod 16)
+    if (tid == 0) {
+      uint32_t off = 0;
+      bool ok = P.stage_bytes > 0;
+      for (int k = P.ndom - 1; k < P.K && ok; k++) {
+        const uint64_t G = s.bufs[P.cnt_databuf[k]] + s.gb[k];
+        const uint32_t mis = (uint32_t)(G & 15);
+        s.so[k] = off + mis;
+        off += (mis + s.tot[k] + 15) & ~15u;
+        if (off > P.stage_bytes) ok = false;
+      }
+      if (!ok)
+        for (int k = 0; k < P.K; k++) s.so[k] = kNoStage;
+      s.misc[1] = ok ? 1u : 0u;
+    }
+    __syncthreads();
   }
 
   lane_init(L, P, g, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-  run_walk<true>(c, s, L, fits, wb16);
+  run_walk<true>(P, c, s, L, fits, wb16);
 
-  report_errors(P, s, L, g, tid);   // barrier inside: nullcnt complete
+  report_errors(P, s.misc, L, g, tid);   // barrier inside: nullcnt + staging complete
   for (int i = tid; i < P.nnodes; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
+  }
+
+  // flush the staged string bytes: one wave per column, aligned 16-byte stores
+  if (P.K > 0 && s.misc[1]) {
+    for (int k = P.ndom - 1 + (int)wave; k < P.K; k += 4) {
+      const uint32_t T = s.tot[k];
+      if (T == 0) continue;
+      flush_column(s.bufs[P.cnt_databuf[k]] + s.gb[k], s.stage + s.so[k], T, lane);
+    }
   }
 }
 

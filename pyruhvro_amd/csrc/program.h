@@ -3,7 +3,19 @@
 // ruhvro/src/fast_decode.rs:73-167).  Built on the host by schema.cpp, run by
 // the interpreter in kernels.hip.  Shared between host and device code.
 #pragma once
+#ifdef __HIPCC_RTC__   // hiprtc has no system headers
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+#else
 #include <stdint.h>
+#endif
 
 namespace rh {
 
@@ -85,6 +97,7 @@ struct KParams {
   uint32_t bpc;              // workgroups per (non-last) chunk
   uint32_t nblocks;
   uint32_t win_bytes;        // LDS bytes reserved for the input window
+  uint32_t stage_bytes;      // LDS bytes reserved for staging string bytes (k_emit; 0 = write HBM directly)
 
   const Op* prog;
   const uint32_t* sym_off;
@@ -94,13 +107,15 @@ struct KParams {
   int32_t ndom;              // row domains (>= 1)
   int32_t nnodes;
   int32_t list_depth;        // max list nesting (LDS rem[] rows)
+  int32_t nbuf;              // output buffers per chunk
+  const int32_t* cnt_databuf;  // [K] string counter -> its BK_DATA buffer id (-1 for row-domain counters)
 
   uint32_t* blocksum;        // [K][nblocks]
   uint32_t* blockbase;       // [K][nblocks] chunk-relative exclusive prefix
   uint64_t* totals;          // [K][k]
   unsigned long long* first_bad;  // lowest failing record index, ~0 if none
   ErrInfo* errinfo;          // [nblocks]
-  void* const* bufptr;       // [nbuf][k]
+  void* const* bufptr;       // [k][nbuf]
   uint32_t* nullcount;       // [nnodes][k]
 };
 

@@ -82,15 +82,15 @@ PyObject* py_free_struct(PyObject*, PyObject* args) {
 }
 
 PyObject* stats_dict(const rh_stats& st) {
-  return Py_BuildValue("{s:K,s:K,s:K,s:I,s:I,s:f,s:f,s:f,s:f,s:f,s:f,s:f}", "records",
+  return Py_BuildValue("{s:K,s:K,s:K,s:I,s:I,s:f,s:f,s:f,s:f,s:f,s:f,s:f,s:I,s:I}", "records",
                        (unsigned long long)st.records, "input_bytes", (unsigned long long)st.input_bytes,
                        "output_bytes", (unsigned long long)st.output_bytes, "chunks", st.chunks, "blocks", st.blocks,
                        "pack_ms", st.pack_ms, "h2d_ms", st.h2d_ms, "size_kernel_ms", st.size_kernel_ms,
                        "scan_kernel_ms", st.scan_kernel_ms, "emit_kernel_ms", st.emit_kernel_ms, "d2h_ms", st.d2h_ms,
-                       "total_ms", st.total_ms);
+                       "total_ms", st.total_ms, "specialized", st.specialized, "lds_bytes", st.lds_bytes);
 }
 
-// decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False)
+// decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)
 //   -> (list[int] addresses of malloc'd ArrowArray structs, stats dict | None)
 PyObject* py_decode(PyObject*, PyObject* args) {
   PyObject *cap, *list;
@@ -98,7 +98,8 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   int device = -1;
   unsigned long long stream = 0;
   int want_stats = 0;
-  if (!PyArg_ParseTuple(args, "OOK|iKp", &cap, &list, &num_chunks, &device, &stream, &want_stats)) return nullptr;
+  int kernel = RH_KERNEL_AUTO;
+  if (!PyArg_ParseTuple(args, "OOK|iKpi", &cap, &list, &num_chunks, &device, &stream, &want_stats, &kernel)) return nullptr;
   rh_schema* s = get_schema(cap);
   if (!s) return nullptr;
   if (!PyList_Check(list)) {
@@ -135,7 +136,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
   rh_opts opts;
   opts.device = device;
-  opts.flags = 0;
+  opts.flags = kernel;
   opts.stream = (void*)(uintptr_t)stream;
   rh_stats st;
   std::memset(&st, 0, sizeof st);
@@ -183,7 +184,7 @@ PyMethodDef methods[] = {
     {"compile_schema", py_compile_schema, METH_VARARGS, "compile_schema(json) -> schema capsule"},
     {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
     {"export_schema", py_export_schema, METH_VARARGS, "export_schema(capsule) -> address of ArrowSchema"},
-    {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False)"},
+    {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
     {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},

@@ -1,0 +1,207 @@
+// Per-schema specialised kernels of the direct-decode path (gfx950).
+//
+// specialize.cpp turns a compiled schema into a tiny translation unit: a struct
+// `Spec` with the schema's constants and a `walk<EMIT>` member that calls the
+// field handlers of walk.h in schema order with constexpr Ops, plus two kernel
+// stubs that instantiate the bodies below.  With every Op a compile-time
+// constant the handlers fold to straight-line code per field: no op fetch, no
+// dispatch, and the per-lane counters (child rows / string bytes) live in
+// registers instead of LDS, which is what lets several workgroups share a CU.
+//
+// Same algorithm, same launch sequence and same KParams as the generic kernels
+// in kernels.hip (k_size -> k_scan -> k_init -> k_emit); only k_size / k_emit
+// are replaced.
+#pragma once
+#include "kernel_common.h"
+
+namespace rh {
+
+// compile-time loop: every array index below is a constant, so the arrays scalarise into registers
+template <int I>
+struct IC { static constexpr int value = I; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <class S>
+struct SCtx {
+  static constexpr int K1 = S::K > 0 ? S::K : 1;
+  mutable uint32_t cnt[K1];                           // per-lane counters (registers)
+  mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
+  uint64_t bufs[S::NBUF > 0 ? S::NBUF : 1];           // this chunk's Arrow buffer addresses (uniform)
+  uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
+  uint32_t so[K1];                                    // LDS staging offset per string counter
+  uint32_t* nullcnt;                                  // LDS [NNODES]
+  uint8_t* stg;                                       // LDS staging area
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  uint32_t lrow, lane;
+  bool wave_live;
+
+  __device__ __forceinline__ uint32_t& counter(int id) const { return cnt[id]; }
+  __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
+  __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
+  __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
+  __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
+  __device__ __forceinline__ uint8_t* stage() const { return stg; }
+  __device__ __forceinline__ void add_nulls(int node, uint32_t n) const { atomicAdd(&nullcnt[node], n); }
+};
+
+// LDS in front of the window: wtot[K][4] | nullcnt[NNODES] | misc[4]   (host mirror: rh_spec_lds_fixed_bytes)
+__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes) {
+  return (uint32_t)(K > 0 ? K : 1) * 4 + (uint32_t)((nnodes + 3) & ~3) + 4;
+}
+
+template <class S>
+struct SpecSmem {
+  uint32_t* wtot;
+  uint32_t* nullcnt;
+  uint32_t* misc;
+  uint8_t* win;
+  uint8_t* stage;
+  __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
+    uint32_t* p = reinterpret_cast<uint32_t*>(smem);
+    wtot = p; p += (S::K > 0 ? S::K : 1) * 4;
+    nullcnt = p; p += ((S::NNODES + 3) & ~3);
+    misc = p; p += 4;
+    win = reinterpret_cast<uint8_t*>(p);
+    stage = win + P.win_bytes + 16;
+  }
+};
+
+template <class S, bool EMIT>
+__device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
+  if (fits) {
+    LdsSrc src{win};
+    S::template walk<EMIT>(c, src, L);
+  } else {
+    GlobalSrc src{P.data + wb16, P.data_len - wb16};
+    S::template walk<EMIT>(c, src, L);
+  }
+}
+
+template <class S>
+__device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
+  static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; c.so[k] = kNoStage; });
+  static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
+  c.nullcnt = s.nullcnt; c.stg = s.stage; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
+  c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
+}
+
+// --------------------------------------------------------------------------
+// size pass: per-workgroup counter sums (+ first malformed record)
+// --------------------------------------------------------------------------
+template <class S>
+__device__ __forceinline__ void spec_size(const KParams& P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SpecSmem<S> s(P, smem);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Geo g = geometry(P, blockIdx.x);
+  const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
+  const uint64_t wb16 = wb & ~15ull;
+  const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
+  if (fits) stage_window(P, s.win, wb16, we, tid);
+  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
+  __syncthreads();
+
+  Lane L;
+  lane_init(L, P, g, wb16, tid);
+  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
+  SCtx<S> c;
+  spec_ctx_init(c, P, s, g, tid);
+  spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+
+  static_for<0, S::K>([&](auto ik) {
+    constexpr int k = decltype(ik)::value;
+    const uint32_t v = wave_sum(c.cnt[k]);
+    if (lane == 0) s.wtot[k * 4 + wave] = v;
+  });
+  report_errors(P, s.misc, L, g, tid);   // contains the barrier that publishes wtot
+  if ((int)tid < S::K)
+    P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
+        s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
+}
+
+// --------------------------------------------------------------------------
+// emit pass: re-size, scan inside the workgroup, materialise, flush staged strings
+// --------------------------------------------------------------------------
+template <class S>
+__device__ __forceinline__ void spec_emit(const KParams& P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SpecSmem<S> s(P, smem);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Geo g = geometry(P, blockIdx.x);
+  const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
+  const uint64_t wb16 = wb & ~15ull;
+  const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
+  if (fits) stage_window(P, s.win, wb16, we, tid);
+  for (int i = tid; i < S::NNODES; i += kBlock) s.nullcnt[i] = 0;
+  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
+
+  Lane L;
+  SCtx<S> c;
+  spec_ctx_init(c, P, s, g, tid);
+  static_for<0, S::NBUF>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    c.bufs[i] = reinterpret_cast<uint64_t>(P.bufptr[(size_t)g.chunk * S::NBUF + i]);
+  });
+  __syncthreads();
+
+  uint32_t tot[SCtx<S>::K1];
+  bool staged = false;
+  if (S::K > 0) {
+    lane_init(L, P, g, wb16, tid);
+    spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+    static_for<0, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      const uint32_t v = c.cnt[k];
+      const uint32_t incl = wave_incl_scan(v, lane);
+      if (lane == 63) s.wtot[k * 4 + wave] = incl;
+      c.cnt[k] = incl - v;
+    });
+    __syncthreads();
+    // every lane derives the (uniform) workgroup totals, bases and staging layout itself: no second barrier
+    uint32_t off = 0;
+    staged = P.stage_bytes > 0;
+    static_for<0, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      const uint32_t w0 = s.wtot[k * 4], w1 = s.wtot[k * 4 + 1], w2 = s.wtot[k * 4 + 2], w3 = s.wtot[k * 4 + 3];
+      c.cnt[k] += (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);   // workgroup-local exclusive prefix
+      tot[k] = w0 + w1 + w2 + w3;
+      c.gb[k] = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
+      if constexpr (k >= S::NDOM - 1) {   // string byte column: staging slot with the destination's 16-byte phase
+        const uint64_t G = c.bufs[S::databuf(k)] + c.gb[k];
+        const uint32_t mis = (uint32_t)(G & 15);
+        c.so[k] = off + mis;
+        off += (mis + tot[k] + 15) & ~15u;
+      }
+    });
+    if (off > P.stage_bytes) staged = false;
+    if (!staged) static_for<0, S::K>([&](auto ik) { c.so[decltype(ik)::value] = kNoStage; });
+  }
+
+  lane_init(L, P, g, wb16, tid);
+  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
+  spec_run_walk<S, true>(P, c, s.win, L, fits, wb16);
+
+  report_errors(P, s.misc, L, g, tid);   // barrier inside: nullcnt + staging complete
+  for (int i = tid; i < S::NNODES; i += kBlock) {
+    const uint32_t v = s.nullcnt[i];
+    if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
+  }
+
+  // flush the staged string bytes: one wave per column, aligned 16-byte stores
+  if (S::K > 0 && staged) {
+    static_for<S::NDOM - 1, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      if (((k - (S::NDOM - 1)) & 3) == (int)wave && tot[k] != 0)
+        flush_column(c.bufs[S::databuf(k)] + c.gb[k], s.stage + c.so[k], tot[k], lane);
+    });
+  }
+}
+
+}  // namespace rh

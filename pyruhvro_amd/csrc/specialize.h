@@ -1,0 +1,26 @@
+// Per-schema kernel specialisation (see specialize.cpp).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "schema.h"
+
+namespace rh {
+
+// HIP source of the specialised k_size / k_emit pair for this schema.
+std::string generate_kernel_source(const CompiledSchema& cs);
+// Content hash of (source + the device headers it includes): the on-disk cache key.
+std::string kernel_cache_key(const std::string& source);
+// Directory of cached code objects: $RUHVRO_HIP_KERNEL_CACHE or <library dir>/_kcache.
+std::string kernel_cache_dir();
+// hiprtc: source -> gfx950 code object (works without a GPU).  Throws std::runtime_error.
+std::vector<char> compile_kernel(const std::string& source, std::string& log);
+// Cached code object, compiling (and storing) on a miss when allowed; empty if absent and !allow_compile.
+std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache);
+
+// Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
+inline uint32_t spec_lds_fixed_words_host(int K, int nnodes) {
+  return (uint32_t)(K > 0 ? K : 1) * 4 + (uint32_t)((nnodes + 3) & ~3) + 4;
+}
+
+}  // namespace rh

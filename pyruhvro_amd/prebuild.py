@@ -1,0 +1,74 @@
+"""Populate the kernel cache (pyruhvro_amd/_kcache/*.hsaco) with schema-specialised kernels.
+
+hiprtc cross-compiles gfx950 without a GPU, so this runs in the build container; the cache travels
+with the tree to the GPU box, where the engine then only loads code objects.  Cache entries are keyed
+by a content hash of the generated source + the device headers, so stale entries are never used.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+from typing import Iterable, List, Tuple
+
+
+def _one(schema_json: str) -> Tuple[bool, str]:
+    from pyruhvro_amd import cabi
+    try:
+        return cabi.prebuild(schema_json), ""
+    except Exception as e:  # noqa: BLE001 - reported to the caller
+        return False, str(e)
+
+
+def prebuild_many(schemas: Iterable[str], jobs: int = 0, verbose: bool = False) -> List[str]:
+    """Compile every schema's kernels (parallel processes).  Returns the list of error messages."""
+    uniq = list(dict.fromkeys(schemas))
+    jobs = jobs or min(len(uniq), os.cpu_count() or 1, 16)
+    errors: List[str] = []
+    if not uniq:
+        return errors
+    if jobs <= 1:
+        results = [_one(s) for s in uniq]
+    else:
+        with ProcessPoolExecutor(max_workers=jobs) as ex:
+            results = list(ex.map(_one, uniq))
+    hits = sum(1 for hit, err in results if hit and not err)
+    for (hit, err), s in zip(results, uniq):
+        if err:
+            errors.append(err)
+    if verbose:
+        print(f"kernel cache: {len(uniq)} schemas, {hits} already cached, {len(uniq) - hits - len(errors)} compiled, "
+              f"{len(errors)} failed")
+    return errors
+
+
+def known_schemas() -> List[str]:
+    """Benchmark schemas + every schema the parity tests decode."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from avrogen.schemas import SCHEMAS
+    out = list(SCHEMAS.values())
+    try:
+        import json
+        import cases
+        for c in cases.wire_cases() + cases.nesting_cases():
+            out.append(c[1])
+        for c in cases.error_cases():
+            out.append(c[1])
+        for c in cases.differential_cases():
+            out.append(c[1])
+        out.append(cases.logical_case()[0])
+        g = json.load(open(os.path.join(root, "tests", "golden", "reference_vectors.json")))
+        out += [json.dumps(s) for s in g["schemas"].values()]
+    except Exception:  # tests/ not present (installed package): benchmark schemas only
+        pass
+    return out
+
+
+if __name__ == "__main__":
+    errs = prebuild_many(known_schemas(), verbose=True)
+    for e in errs:
+        print(e[:2000])
+    sys.exit(1 if errs else 0)

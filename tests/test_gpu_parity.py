@@ -17,6 +17,17 @@ from pyruhvro_amd import cabi
 
 pytestmark = pytest.mark.gpu
 
+KERNELS = {"generic": cabi.KERNEL_GENERIC, "specialized": cabi.KERNEL_SPECIALIZED}
+
+
+@pytest.fixture(params=sorted(KERNELS), autouse=True)
+def kernel(request):
+    """Every parity test runs twice: the generic schema-program interpreter kernels and the
+    schema-specialised kernels (same field handlers, walk.h) must both match the oracle."""
+    old = P.set_kernel_mode(request.param)
+    yield KERNELS[request.param]
+    P.set_kernel_mode(old)
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")
 
 
@@ -30,10 +41,14 @@ def _check(recs, schema, k):
     return got
 
 
-def test_native_library_is_the_path_that_runs():
+def test_native_library_is_the_path_that_runs(kernel):
     assert P.device_count() >= 1
     maps = open("/proc/self/maps").read()
     assert "libruhvro_hip.so" in maps and "_pyruhvro.so" in maps
+    recs = synth.records("full", 500)
+    _, st = P.deserialize_array_threaded_with_stats(recs, SCHEMAS["full"], 2)
+    assert st["specialized"] == (1 if kernel == cabi.KERNEL_SPECIALIZED else 0)
+    assert st["records"] == 500 and st["emit_kernel_ms"] > 0
 
 
 def test_golden_vectors():
@@ -112,14 +127,14 @@ def test_chunk_semantics():
     assert P.deserialize_array_threaded_spawn(recs, SCHEMAS["full"], 3)[1].equals(P.deserialize_array_threaded(recs, SCHEMAS["full"], 3)[1])
 
 
-def test_input_forms():
+def test_input_forms(kernel):
     recs = synth.records("cfg3", 300)
     a = P.deserialize_array_threaded(recs, SCHEMAS["cfg3"], 2)
     b = P.deserialize_array_threaded([bytearray(r) for r in recs], SCHEMAS["cfg3"], 2)   # bytearray is copied (PyBackedBytes)
     for x, y in zip(a, b):
         assert_batches_identical(x, y)
     data, offsets = c_walker.pack(recs)
-    c = cabi.decode_packed(data, offsets, SCHEMAS["cfg3"], 2)
+    c = cabi.decode_packed(data, offsets, SCHEMAS["cfg3"], 2, kernel=kernel)
     for x, y in zip(a, c):
         assert_batches_identical(x, y)
 
@@ -135,10 +150,10 @@ def test_records_larger_than_the_lds_window():
 
 
 @pytest.mark.parametrize("name,n", [("flat4", 1_000_000), ("cfg3", 1_000_000), ("full", 1_000_000)])
-def test_baseline_configs_1m(name, n):
+def test_baseline_configs_1m(name, n, kernel):
     """BASELINE.json configs 2-4 at 1M records: full buffer identity against the oracle."""
     data, offsets = fastgen.generate(name, n)
-    got = cabi.decode_packed(data, offsets, SCHEMAS[name], 8)
+    got = cabi.decode_packed(data, offsets, SCHEMAS[name], 8, kernel=kernel)
     cs = c_walker.CompiledSchema(SCHEMAS[name])
     exp = c_walker.decode_packed(cs, data, offsets, 8, threaded=True)
     assert [b.num_rows for b in got] == [125_000] * 8
@@ -146,11 +161,11 @@ def test_baseline_configs_1m(name, n):
         assert_batches_identical(g, e)
 
 
-def test_full_schema_10m_properties():
+def test_full_schema_10m_properties(kernel):
     """BASELINE.json config 4 at full size: size-independent properties + oracle equality per chunk."""
     n = 10_000_000
     data, offsets = fastgen.generate("full", n)
-    got = cabi.decode_packed(data, offsets, SCHEMAS["full"], 8)
+    got = cabi.decode_packed(data, offsets, SCHEMAS["full"], 8, kernel=kernel)
     assert sum(b.num_rows for b in got) == n and len(got) == 8
     cs = c_walker.CompiledSchema(SCHEMAS["full"])
     exp = c_walker.decode_packed(cs, data, offsets, 8, threaded=True)
@@ -170,5 +185,5 @@ def test_full_schema_10m_properties():
             assert_identical(g.column(col), e.column(col), col)
     assert total_str > 0
     # every input byte of every string column is accounted for: re-decode of a slice equals the slice
-    part = cabi.decode_packed(data[: int(offsets[1000])], offsets[:1001], SCHEMAS["full"], 1)[0]
+    part = cabi.decode_packed(data[: int(offsets[1000])], offsets[:1001], SCHEMAS["full"], 1, kernel=kernel)[0]
     assert part.equals(got[0].slice(0, 1000))
