@@ -34,17 +34,42 @@ __device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
 }
 
 // Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction).
+// The loads of a batch of 8 vectors per thread are ALL issued before the first LDS store, so a
+// workgroup pays one HBM round trip per 32 KiB of window instead of one per 4 KiB.
 __device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uint64_t wb16, uint64_t we, uint32_t tid) {
   const uint32_t nvec = (uint32_t)((we - wb16 + 15) >> 4);
   const uint8_t* g = P.data + wb16;
-  for (uint32_t i = tid; i < nvec; i += kBlock) {
-    const uint64_t pos = wb16 + ((uint64_t)i << 4);
-    if (pos + 16 <= P.data_len) {
-      reinterpret_cast<v4u*>(win)[i] = *reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(g + ((size_t)i << 4)));
-    } else {
-      for (uint32_t j = 0; j < 16; j++) win[(i << 4) + j] = pos + j < P.data_len ? g[((size_t)i << 4) + j] : 0;
+  const uint32_t nfull = (uint32_t)(wb16 + ((uint64_t)nvec << 4) <= P.data_len ? nvec : (P.data_len - wb16) >> 4);   // whole vectors inside the payload
+  constexpr int kBatch = 8;
+  for (uint32_t base = 0; base < nfull; base += kBatch * kBlock) {
+    v4u r[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; j++) {
+      const uint32_t i = base + j * kBlock + tid;
+      if (i < nfull) r[j] = *reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(g + ((size_t)i << 4)));
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; j++) {
+      const uint32_t i = base + j * kBlock + tid;
+      if (i < nfull) reinterpret_cast<v4u*>(win)[i] = r[j];
     }
   }
+  if (nfull < nvec && tid < 16) {   // ragged tail of the payload: bytes, zero-filled past the end
+    const uint64_t pos = wb16 + ((uint64_t)nfull << 4);
+    win[(nfull << 4) + tid] = pos + tid < P.data_len ? g[((size_t)nfull << 4) + tid] : 0;
+  }
+}
+
+// lane set-up from record offsets the caller already holds in registers (loaded once, together with
+// the window bounds, so the workgroup pays a single dependent round trip before the window load)
+__device__ __forceinline__ void lane_init_from(Lane& L, const Geo& g, uint64_t o0, uint64_t o1, uint64_t wb16, uint32_t tid) {
+  L.live = tid < g.nrec;
+  L.pres = L.live;
+  L.err = 0;
+  L.edetail = 0;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0;
+  L.cur = L.live ? (uint32_t)(o0 - wb16) : 0;
+  L.end = L.live ? (uint32_t)(o1 - wb16) : 0;
 }
 
 __device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& g, uint64_t wb16, uint32_t tid) {

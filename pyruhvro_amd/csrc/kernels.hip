@@ -55,7 +55,10 @@ struct ICtx {
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
   __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
   __device__ __forceinline__ uint8_t* stage() const { return stg; }
-  __device__ __forceinline__ void add_nulls(int node, uint32_t n) const { atomicAdd(&nullcnt[node], n); }
+  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
+    if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
+  }
+  __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
 
 // --------------------------------------------------------------------------

@@ -117,6 +117,7 @@ struct KParams {
   ErrInfo* errinfo;          // [nblocks]
   void* const* bufptr;       // [k][nbuf]
   uint32_t* nullcount;       // [nnodes][k]
+  unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
 };
 
 }  // namespace rh

@@ -27,6 +27,34 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// Phase timing (RUHVRO_HIP_PROFILE=1): lane 0 of every wave adds the shader-clock cycles between
+// marks to P.prof[slot]; the host prints per-wave means.  Compiled out otherwise.
+#ifdef RH_PROFILE
+#define RH_MARK(slot)                                   \
+  do {                                                  \
+    const unsigned long long _t = clock64();            \
+    _pd[slot] = _t - _tprev;                            \
+    _tprev = _t;                                        \
+  } while (0)
+#define RH_MARK_INIT                                    \
+  unsigned long long _pd[20];                           \
+  for (int _i = 0; _i < 20; _i++) _pd[_i] = 0;          \
+  unsigned long long _tprev = clock64()
+// one fire-and-forget atomic per slot per wave, spread over 64 rows to keep L2 contention out of the picture
+#define RH_MARK_FLUSH                                                                                     \
+  do {                                                                                                    \
+    if ((threadIdx.x & 63) == 0 && P.prof) {                                                              \
+      unsigned long long* _row = P.prof + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63) * 32;      \
+      for (int _i = 0; _i < 20; _i++)                                                                     \
+        if (_pd[_i]) atomicAdd(&_row[_i], _pd[_i]);                                                       \
+    }                                                                                                     \
+  } while (0)
+#else
+#define RH_MARK(slot) do {} while (0)
+#define RH_MARK_INIT do {} while (0)
+#define RH_MARK_FLUSH do {} while (0)
+#endif
+
 template <class S>
 struct SCtx {
   static constexpr int K1 = S::K > 0 ? S::K : 1;
@@ -35,6 +63,7 @@ struct SCtx {
   uint64_t bufs[S::NBUF > 0 ? S::NBUF : 1];           // this chunk's Arrow buffer addresses (uniform)
   uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
   uint32_t so[K1];                                    // LDS staging offset per string counter
+  mutable uint32_t nacc[S::NNODES];                   // nulls seen by this wave per node (wave-uniform)
   uint32_t* nullcnt;                                  // LDS [NNODES]
   uint8_t* stg;                                       // LDS staging area
   const uint32_t* sym_off;
@@ -48,7 +77,8 @@ struct SCtx {
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
   __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
   __device__ __forceinline__ uint8_t* stage() const { return stg; }
-  __device__ __forceinline__ void add_nulls(int node, uint32_t n) const { atomicAdd(&nullcnt[node], n); }
+  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { nacc[node] += n; }
+  __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
 
 // LDS in front of the window: wtot[K][4] | nullcnt[NNODES] | misc[4]   (host mirror: rh_spec_lds_fixed_bytes)
@@ -88,6 +118,7 @@ template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
   static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; c.so[k] = kNoStage; });
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
+  static_for<0, S::NNODES>([&](auto in) { c.nacc[decltype(in)::value] = 0; });
   c.nullcnt = s.nullcnt; c.stg = s.stage; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
 }
@@ -100,20 +131,26 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  RH_MARK_INIT;
   const Geo g = geometry(P, blockIdx.x);
+  uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
+  if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   if (fits) stage_window(P, s.win, wb16, we, tid);
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
+  RH_MARK(16);
 
   Lane L;
-  lane_init(L, P, g, wb16, tid);
+  lane_init_from(L, g, o0, o1, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
+  RH_MARK(17);
   spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+  RH_MARK(18);
 
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
@@ -124,6 +161,8 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   if ((int)tid < S::K)
     P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
+  RH_MARK(19);
+  RH_MARK_FLUSH;
 }
 
 // --------------------------------------------------------------------------
@@ -134,28 +173,39 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  RH_MARK_INIT;
   const Geo g = geometry(P, blockIdx.x);
+  uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
+  if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
-  const uint64_t wb16 = wb & ~15ull;
-  const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
-  if (fits) stage_window(P, s.win, wb16, we, tid);
-  for (int i = tid; i < S::NNODES; i += kBlock) s.nullcnt[i] = 0;
-  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
-
   Lane L;
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
+  // uniform per-workgroup inputs, requested before the window so their latency hides behind it
   static_for<0, S::NBUF>([&](auto ii) {
     constexpr int i = decltype(ii)::value;
     c.bufs[i] = reinterpret_cast<uint64_t>(P.bufptr[(size_t)g.chunk * S::NBUF + i]);
   });
+  static_for<0, S::K>([&](auto ik) {
+    constexpr int k = decltype(ik)::value;
+    c.gb[k] = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
+  });
+  const uint64_t wb16 = wb & ~15ull;
+  const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
+  RH_MARK(0);
+  if (fits) stage_window(P, s.win, wb16, we, tid);
+  for (int i = tid; i < S::NNODES; i += kBlock) s.nullcnt[i] = 0;
+  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
+  RH_MARK(1);
 
   uint32_t tot[SCtx<S>::K1];
   bool staged = false;
   if (S::K > 0) {
-    lane_init(L, P, g, wb16, tid);
+    lane_init_from(L, g, o0, o1, wb16, tid);
+    RH_MARK(2);
     spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+    RH_MARK(3);
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
       const uint32_t v = c.cnt[k];
@@ -163,7 +213,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       if (lane == 63) s.wtot[k * 4 + wave] = incl;
       c.cnt[k] = incl - v;
     });
+    RH_MARK(4);
     __syncthreads();
+    RH_MARK(5);
     // every lane derives the (uniform) workgroup totals, bases and staging layout itself: no second barrier
     uint32_t off = 0;
     staged = P.stage_bytes > 0;
@@ -172,7 +224,6 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       const uint32_t w0 = s.wtot[k * 4], w1 = s.wtot[k * 4 + 1], w2 = s.wtot[k * 4 + 2], w3 = s.wtot[k * 4 + 3];
       c.cnt[k] += (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);   // workgroup-local exclusive prefix
       tot[k] = w0 + w1 + w2 + w3;
-      c.gb[k] = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
       if constexpr (k >= S::NDOM - 1) {   // string byte column: staging slot with the destination's 16-byte phase
         const uint64_t G = c.bufs[S::databuf(k)] + c.gb[k];
         const uint32_t mis = (uint32_t)(G & 15);
@@ -184,11 +235,19 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     if (!staged) static_for<0, S::K>([&](auto ik) { c.so[decltype(ik)::value] = kNoStage; });
   }
 
-  lane_init(L, P, g, wb16, tid);
+  RH_MARK(6);
+  lane_init_from(L, g, o0, o1, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
   spec_run_walk<S, true>(P, c, s.win, L, fits, wb16);
+  RH_MARK(7);
+  if (lane == 0)
+    static_for<0, S::NNODES>([&](auto in) {
+      constexpr int i = decltype(in)::value;
+      if (c.nacc[i]) atomicAdd(&s.nullcnt[i], c.nacc[i]);
+    });
 
   report_errors(P, s.misc, L, g, tid);   // barrier inside: nullcnt + staging complete
+  RH_MARK(8);
   for (int i = tid; i < S::NNODES; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
@@ -202,6 +261,8 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
         flush_column(c.bufs[S::databuf(k)] + c.gb[k], s.stage + c.so[k], tot[k], lane);
     });
   }
+  RH_MARK(9);
+  RH_MARK_FLUSH;
 }
 
 }  // namespace rh

@@ -49,13 +49,35 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // --------------------------------------------------------------------------
 // byte sources.  Positions are relative to the workgroup's window base.
-// gfx950 services unaligned DS / global accesses in hardware, so an 8-byte
-// read at any byte position is ONE ds_read_b64 / global_load_dwordx2.
+//
+// Measured on MI355X (tools/ldslat.hip): a DS read that is not naturally aligned (ds_read_b64 off an
+// 8-byte boundary, ds_read_b32 off a 4-byte boundary) is serviced one lane per cycle -- ~64 LDS cycles
+// per wave instruction, serialised across every wave of the CU (128 cycles/step for one wave, >1000 with
+// 16 waves) -- while aligned reads pipeline at ~64 cycles latency regardless of load.  So the LDS window
+// is only ever read with ALIGNED dword reads and the bytes are funnelled into place with v_alignbyte.
+// Global memory has no such cliff (tools/gmemalign.hip), so GlobalSrc reads unaligned directly.
 // --------------------------------------------------------------------------
 struct LdsSrc {
-  const uint8_t* w;   // LDS window; >= 8 readable bytes past the last record
+  const uint8_t* w;   // LDS window, 16-byte aligned; >= 12 readable bytes past the last record
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return w[p]; }
-  __device__ __forceinline__ uint64_t ld8(uint32_t p) const { return *reinterpret_cast<const u64u*>(w + p); }
+  // 8 bytes at any byte position: three aligned dwords (ds_read2_b32 + ds_read_b32), two v_alignbyte
+  __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  // >= 5 valid bytes (a 1-byte union branch + a varint of <= 4 bytes) from ONE ds_read2_b32
+  __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    const uint32_t d0 = a[0], d1 = a[1];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
 };
 
 struct GlobalSrc {
@@ -68,6 +90,7 @@ struct GlobalSrc {
     for (uint32_t j = 0; j < 8 && (uint64_t)p + j < lim; j++) x |= (uint64_t)g[p + j] << (8 * j);
     return x;
   }
+  __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
 };
 
 // Arrow buffers live in HBM: typed global-address-space accessors keep the compiler from emitting
@@ -115,16 +138,32 @@ struct Lane {
   uint32_t cur, end;   // byte cursor / record end, relative to the window base (cur <= end always)
   uint32_t err;        // ErrCode, 0 = ok
   int64_t edetail;
-  bool live, pres;
+  bool live, pres;     // an errored lane is dead: live = pres = false and its saved bits are cleared
   uint32_t pstk;       // saved `pres` bits   (nullable record / union / list)
   uint32_t lstk;       // saved `live` bits   (list)
   uint64_t sstk;       // saved union selectors, 8 bits each
 };
 
+// First error of a record (the reference's `?` at fast_decode.rs:827): remember it and kill the lane so
+// that every later handler sees it as not-live (nothing is emitted or counted for it any more).
+__device__ __forceinline__ void fail(Lane& L, uint32_t code, int64_t detail = 0) {
+  L.err = code;
+  L.edetail = detail;
+  L.live = false;
+  L.pres = false;
+  L.pstk = 0;
+  L.lstk = 0;
+}
+
 // --------------------------------------------------------------------------
 // primitive readers (fast_decode.rs:845-922)
+//
+// Every field starts with ONE unaligned 8-byte read at the cursor, decoded branch-free for the
+// common wire forms (single-byte union branch, varints of <= 4 / <= 8 bytes inside the record).
+// Anything else -- longer or non-canonical varints, a varint running past the record end, bad
+// branch bytes -- takes the byte-at-a-time path below, which follows the reference's exact error
+// order.  That path sits behind a wave-uniform `__any` so the common case never touches EXEC.
 // --------------------------------------------------------------------------
-// byte-at-a-time form with the reference's exact error order (854-869)
 template <class Src>
 __device__ __forceinline__ uint32_t rd_varint_slow(const Src& src, uint32_t& cur, uint32_t end, int64_t& out) {
   uint64_t r = 0;
@@ -141,15 +180,23 @@ __device__ __forceinline__ uint32_t rd_varint_slow(const Src& src, uint32_t& cur
   return E_OK;
 }
 
-// Decode a zig-zag LEB128 varint that starts at bit 0 of x (x holds `nx` valid bytes, `avail` bytes
-// remain in the record).  Branch-free for varints of <= nx bytes; returns false when the slow path
-// must decide (longer varint, or one that runs past the record end).
-__device__ __forceinline__ bool varint_from_bits(uint64_t x, uint32_t nx, uint32_t avail, int64_t& out, uint32_t& n) {
-  const uint64_t t = ~x & 0x8080808080808080ull;   // bit 7 of every byte WITHOUT a continuation flag
+// zig-zag LEB128 varint of <= 4 bytes at bit 0 of y: raw (pre-zigzag) 28-bit value and byte length.
+__device__ __forceinline__ bool varint32(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
+  const uint32_t t = ~y & 0x80808080u;            // bit 7 of every byte WITHOUT a continuation flag
+  n = (uint32_t)(__ffs((int)t) + 7) >> 3;         // 1..4, 0 when all four bytes continue
+  y &= t ^ (t - 1);                               // keep bytes 0..n-1
+  y = ((y & 0x7F007F00u) >> 1) | (y & 0x007F007Fu);
+  raw = ((y & 0x3FFF0000u) >> 2) | (y & 0x00003FFFu);
+  return t != 0 && n <= avail;
+}
+
+// same for <= nx (<= 8) bytes at bit 0 of x, full 64-bit value
+__device__ __forceinline__ bool varint64(uint64_t x, uint32_t nx, uint32_t avail, int64_t& out, uint32_t& n) {
+  const uint64_t t = ~x & 0x8080808080808080ull;
   if (t == 0) return false;
   n = ((uint32_t)__builtin_ctzll(t) >> 3) + 1;
   if (n > nx || n > avail) return false;
-  x &= t ^ (t - 1);                                // keep bytes 0..n-1
+  x &= t ^ (t - 1);
   x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
   x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
   x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
@@ -160,39 +207,68 @@ __device__ __forceinline__ bool varint_from_bits(uint64_t x, uint32_t nx, uint32
 template <class Src>
 __device__ __forceinline__ uint32_t rd_varint(const Src& src, uint32_t& cur, uint32_t end, int64_t& out) {
   uint32_t n;
-  if (varint_from_bits(src.ld8(cur), 8, end - cur, out, n)) { cur += n; return E_OK; }
+  if (varint64(src.ld8(cur), 8, end - cur, out, n)) { cur += n; return E_OK; }
   return rd_varint_slow(src, cur, end, out);
 }
 
-// union_branch (585-593) followed by the value's leading varint, from ONE 8-byte read when both fit.
-// Returns isval; when isval and `want_varint`, v holds the varint that follows the branch.
+// exact form of [union_branch (585-593)] [value varint (854-869)] at L.cur; advances L.cur, fails the lane
 template <class Src>
-__device__ __forceinline__ bool rd_branch_then_varint(const Src& src, Lane& L, bool null_first, bool want_varint, int64_t& v) {
-  const uint64_t x = src.ld8(L.cur);
-  const uint32_t avail = L.end - L.cur;
-  const uint32_t b0 = (uint32_t)x & 0xFF;
-  if (avail >= 1 && (b0 == 0 || b0 == 2)) {        // branch 0 / 1, single byte
-    const bool isval = (b0 == 0) ? !null_first : null_first;
-    L.cur += 1;
-    if (isval && want_varint) {
-      uint32_t n;
-      if (varint_from_bits(x >> 8, 7, avail - 1, v, n)) L.cur += n;
-      else {
-        uint32_t e = rd_varint_slow(src, L.cur, L.end, v);
-        if (e) L.err = e;
-      }
-    }
-    return isval;
+__device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nullable, bool null_first, bool want_varint, int64_t& v) {
+  bool isval = true;
+  if (nullable) {
+    int64_t idx = 0;
+    const uint32_t e = rd_varint_slow(src, L.cur, L.end, idx);
+    if (e) { fail(L, e); return false; }
+    if (idx != 0 && idx != 1) { fail(L, E_BRANCH, idx); return false; }
+    isval = (idx == 0) ? !null_first : null_first;
   }
-  int64_t idx = 0;
-  uint32_t e = rd_varint_slow(src, L.cur, L.end, idx);
-  if (e) { L.err = e; return false; }
-  if (idx != 0 && idx != 1) { L.err = E_BRANCH; L.edetail = idx; return false; }
-  const bool isval = (idx == 0) ? !null_first : null_first;
   if (isval && want_varint) {
-    e = rd_varint(src, L.cur, L.end, v);
-    if (e) L.err = e;
+    const uint32_t e = rd_varint(src, L.cur, L.end, v);
+    if (e) { fail(L, e); return false; }
   }
+  return isval;
+}
+
+// Head of a field for the lanes with `dec`: an optional single-byte null-union branch and an optional
+// varint (`wide`: may need more than 28 bits).  Returns isval (false for lanes without `dec`); v is the
+// varint when isval && want_varint.  L.cur moves past what was read.
+template <class Src>
+__device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
+                                         bool wide, int64_t& v) {
+  if (!nullable && !want_varint) return dec;
+  const uint64_t x = (want_varint && wide) ? src.ld8(L.cur) : src.ld5(L.cur);
+  const uint32_t avail = L.end - L.cur;
+  uint32_t skip = 0;
+  bool okb = true, isval = dec;
+  uint64_t y = x;
+  if (nullable) {
+    const uint32_t b0 = (uint32_t)x & 0xFFu;
+    okb = avail != 0 && (b0 & 0xFDu) == 0;          // branch 0 or 1 as a single byte (0x00 / 0x02)
+    isval = dec && (b0 == (null_first ? 2u : 0u));
+    skip = 1;
+    y = x >> 8;
+  }
+  uint32_t n = 0;
+  bool okv = true;
+  if (want_varint) {
+    const uint32_t av = avail - skip;               // wraps only when okb is false
+    if (wide) {
+      okv = varint64(y, nullable ? 7 : 8, av, v, n);
+    } else {
+      uint32_t raw;
+      okv = varint32((uint32_t)y, av, raw, n);
+      v = (int64_t)(int32_t)((raw >> 1) ^ (0u - (raw & 1u)));
+    }
+  }
+  const bool slow = dec && (!okb || (isval && !okv));
+  uint32_t adv = skip + ((isval && want_varint) ? n : 0u);
+  if (__any(slow)) {
+    if (slow) {
+      isval = read_head_slow(src, L, nullable, null_first, want_varint, v);
+      adv = 0;
+    }
+  }
+  L.cur += dec ? adv : 0u;
   return isval;
 }
 
@@ -204,7 +280,8 @@ __device__ __forceinline__ bool rd_branch_then_varint(const Src& src, Lane& L, b
 //   uint32_t gbase(int id)      chunk-relative base of this workgroup for counter id
 //   uint32_t stage_off(int id)  LDS staging offset of string counter id (kNoStage = write to HBM directly)
 //   uint8_t* stage()            LDS staging area
-//   void add_nulls(int node, uint32_t n)
+//   void add_nulls_wave(int node, uint32_t n)   n is wave-uniform (called by every lane)
+//   void add_nulls_lane(int node)               one null row of this lane (child domains)
 //   lrow, lane, wave_live, sym_off, sym_data
 // --------------------------------------------------------------------------
 constexpr uint32_t kNoStage = 0xFFFFFFFFu;
@@ -219,16 +296,14 @@ template <bool EMIT, class Ctx>
 __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool act, bool valid, uint32_t row) {
   if (!EMIT) return;
   if (!(op.flags & F_CAN_NULL)) return;
-  if (op.dom == 0) {
+  if (op.dom == 0) {   // rows == lanes: one ballot, one 64-bit store per wavefront
     const uint64_t m = __ballot(valid);
     const uint64_t nm = __ballot(act && !valid);
-    if (c.lane == 0 && c.wave_live) {
-      st_global<uint64_t>(c.buf(op.buf0), c.lrow >> 6, m);
-      if (nm) c.add_nulls(op.node, (uint32_t)__popcll(nm));
-    }
+    if (c.lane == 0 && c.wave_live) st_global<uint64_t>(c.buf(op.buf0), c.lrow >> 6, m);
+    c.add_nulls_wave(op.node, (uint32_t)__popcll(nm));
   } else if (act) {
     if (valid) atomic_or_global(c.buf(op.buf0), row >> 5, 1u << (row & 31));
-    else c.add_nulls(op.node, 1u);
+    else c.add_nulls_lane(op.node);
   }
 }
 
@@ -238,40 +313,32 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
 // int/long/float/double/boolean/date/timestamp leaf, optionally Nullable* (424-432, 434-473)
 template <bool EMIT, class Src, class Ctx>
 __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
+  const bool act = L.live;
   const bool dec = act && L.pres;
   const bool is_int = op.a == FK_I32 || op.a == FK_I64;
-  bool isval = dec;
   int64_t v = 0;
-  bool have_v = false;
-  if ((op.flags & F_NULLABLE) && dec) {
-    isval = rd_branch_then_varint(src, L, (op.flags & F_NULL_FIRST) != 0, is_int, v);
-    have_v = true;
-  }
-  uint64_t bits = 0;
-  if (dec && isval && L.err == 0) {
-    if (is_int) {
-      if (!have_v) {
-        uint32_t e = rd_varint(src, L.cur, L.end, v);
-        if (e) L.err = e;
-      }
-      bits = op.a == FK_I32 ? (uint64_t)(uint32_t)(int32_t)v : (uint64_t)v;   // `as i32` truncates (424,430)
-    } else if (op.a == FK_F32) {
-      if (L.end - L.cur < 4) L.err = E_EOB_F32;
-      else { bits = (uint32_t)src.ld8(L.cur); L.cur += 4; }
-    } else if (op.a == FK_F64) {
-      if (L.end - L.cur < 8) L.err = E_EOB_F64;
-      else { bits = src.ld8(L.cur); L.cur += 8; }
-    } else {   // FK_BOOL, 893-900
-      if (L.cur >= L.end) L.err = E_EOB;
-      else {
-        uint32_t b = src.ld1(L.cur++);
-        if (b > 1) { L.err = E_BOOL; L.edetail = b; }
-        bits = b;
-      }
+  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
+                               op.a == FK_I64, v);
+  uint64_t bits;
+  bool valid;
+  if (is_int) {
+    valid = isval && L.live;
+    bits = op.a == FK_I32 ? (uint64_t)(uint32_t)(int32_t)v : (uint64_t)v;   // `as i32` truncates (424,430)
+  } else {
+    const uint64_t x = op.a == FK_F64 ? src.ld8(L.cur) : op.a == FK_F32 ? src.ld5(L.cur) : (uint64_t)src.ld1(L.cur);
+    const uint32_t avail = L.end - L.cur;
+    const uint32_t need = op.a == FK_F32 ? 4u : op.a == FK_F64 ? 8u : 1u;
+    const bool want = isval && L.live;
+    const bool eob = want && avail < need;
+    bits = op.a == FK_F32 ? (uint64_t)(uint32_t)x : op.a == FK_F64 ? x : (x & 0xFFu);
+    const bool badb = want && !eob && op.a == FK_BOOL && bits > 1;   // read_bool, 893-900
+    if (__any(eob || badb)) {
+      if (eob) fail(L, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
+      else if (badb) fail(L, E_BOOL, (int64_t)bits);
     }
+    valid = want && L.live;
+    L.cur += valid ? need : 0u;
   }
-  const bool valid = dec && isval && L.err == 0;
   if (!valid) bits = 0;   // zero under nulls (arrow-rs append_null)
   uint32_t row = 0;
   if (EMIT) {
@@ -294,37 +361,33 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
 // string leaf / map key (429, 454-457, 752, read_string 902-922) and enum -> symbol text (570-578)
 template <bool EMIT, class Src, class Ctx>
 __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
+  const bool act = L.live;
   const bool dec = act && L.pres;
-  bool isval = dec;
   int64_t v = 0;
-  bool have_v = false;
-  if ((op.flags & F_NULLABLE) && dec) {
-    isval = rd_branch_then_varint(src, L, (op.flags & F_NULL_FIRST) != 0, true, v);
-    have_v = true;
-  }
+  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
+  const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
-  if (dec && isval && L.err == 0) {
-    if (!have_v) {
-      uint32_t e = rd_varint(src, L.cur, L.end, v);
-      if (e) L.err = e;
+  if (op.code == OP_STRING) {
+    const bool neg = want && v < 0;
+    const bool eob = want && !neg && (uint64_t)v > (uint64_t)(L.end - L.cur);
+    if (__any(neg || eob)) {
+      if (neg) fail(L, E_NEGLEN);
+      else if (eob) fail(L, E_EOB_STR);
     }
-    if (L.err == 0) {
-      if (op.code == OP_STRING) {
-        if (v < 0) L.err = E_NEGLEN;
-        else if ((uint64_t)(L.end - L.cur) < (uint64_t)v) L.err = E_EOB_STR;
-        else { len = (uint32_t)v; spos = L.cur; L.cur += len; }
-      } else {
-        if ((uint64_t)v >= (uint64_t)op.c) { L.err = E_ENUM; L.edetail = v; }
-        else {
-          spos = c.sym_off[op.b + (int32_t)v];
-          len = c.sym_off[op.b + (int32_t)v + 1] - spos;
-        }
-      }
+    len = (want && L.live) ? (uint32_t)v : 0u;
+    spos = L.cur;
+    L.cur += len;
+  } else {
+    const bool oor = want && (uint64_t)v >= (uint64_t)op.c;
+    if (__any(oor)) {
+      if (oor) fail(L, E_ENUM, v);
+    }
+    if (want && L.live) {
+      spos = c.sym_off[op.b + (int32_t)v];
+      len = c.sym_off[op.b + (int32_t)v + 1] - spos;
     }
   }
-  const bool valid = dec && isval && L.err == 0;
-  if (!valid) len = 0;
+  const bool valid = want && L.live;
   uint32_t& bo = c.counter(op.a);
   const uint32_t o = bo;
   uint32_t row = 0;
@@ -347,20 +410,19 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
       }
     }
   }
-  if (act) bo = o + len;
+  bo = o + len;   // len == 0 for every lane that does not carry a value
   put_validity<EMIT>(c, op, act, valid, row);
 }
 
 // NullableRecord (482-485 + 595-616): a null record null-fills its children
 template <bool EMIT, class Src, class Ctx>
 __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
+  const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   const bool dec = act && L.pres;
-  bool isval = dec;
-  int64_t dummy;
-  if (dec) isval = rd_branch_then_varint(src, L, (op.flags & F_NULL_FIRST) != 0, false, dummy);
-  const bool valid = dec && isval && L.err == 0;
+  int64_t dummy = 0;
+  const bool isval = read_head(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.pres = valid;
 }
@@ -372,18 +434,18 @@ __device__ __forceinline__ void h_rec_end(Lane& L) {
 // UnionDecoder::decode / append_null (643-668): selected variant decodes, every other one null-fills
 template <bool EMIT, class Src, class Ctx>
 __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
+  const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   L.sstk = (L.sstk << 8) | 0xFFull;
   const bool dec = act && L.pres;
-  uint32_t tidv = 0;
-  if (dec) {
-    int64_t idx = 0;
-    uint32_t e = rd_varint(src, L.cur, L.end, idx);
-    if (e) L.err = e;
-    else if (idx < 0 || idx >= (int64_t)op.a) { L.err = E_UNION; L.edetail = idx; }
-    else { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
+  int64_t idx = 0;
+  const bool got = read_head(src, L, dec, false, false, true, false, idx) && L.live;
+  const bool oor = got && (idx < 0 || idx >= (int64_t)op.a);
+  if (__any(oor)) {
+    if (oor) fail(L, E_UNION, idx);
   }
+  uint32_t tidv = 0;
+  if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
   if (EMIT && act) st_global<int8_t>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
 }
 __device__ __forceinline__ void h_variant(Lane& L, const Op& op) {
@@ -398,61 +460,80 @@ __device__ __forceinline__ void h_union_end(Lane& L) {
 // ListDecoder / MapDecoder (+ Nullable*), 487-496, 703-770
 template <bool EMIT, class Src, class Ctx>
 __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
+  const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
   const bool dec = act && L.pres;
-  bool isval = dec;
-  int64_t dummy;
-  if ((op.flags & F_NULLABLE) && dec) isval = rd_branch_then_varint(src, L, (op.flags & F_NULL_FIRST) != 0, false, dummy);
-  const bool valid = dec && isval && L.err == 0;
+  int64_t dummy = 0;
+  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.live = valid;      // only rows that really carry a list enter the block loop
   L.pres = valid;
   c.remaining(op.c) = 0;
 }
 
-// read_block_count (689-700).  Returns true while any lane of the wave still has an item (wave-uniform).
+// read_block_count (689-700), exact form: negative counts carry a byte size, i64::MIN is an empty block
+template <class Src, class Ctx>
+__device__ __forceinline__ void list_next_slow(const Ctx& c, const Src& src, Lane& L, const Op& op, uint32_t& rm) {
+  for (;;) {
+    int64_t n = 0;
+    uint32_t e = rd_varint(src, L.cur, L.end, n);
+    if (e) { fail(L, e); return; }
+    if (n < 0) {
+      int64_t bsz;
+      e = rd_varint(src, L.cur, L.end, bsz);   // block byte size, ignored
+      if (e) { fail(L, e); return; }
+      n = (int64_t)(0 - (uint64_t)n);
+    }
+    if (n == 0) { L.live = false; return; }
+    if (n < 0) continue;                         // i64::MIN negates to itself: `0..n` is empty
+    // Clamp the trip count: with m = min wire bytes per item and R bytes left, no more than R/m
+    // items can decode, so item R/m+1 raises the same error the reference hits.
+    const uint64_t R = L.end - L.cur;
+    if (op.buf2 /*min wire bytes per item*/ > 0) {
+      const uint64_t cap = R / (uint32_t)op.buf2 + 1;
+      rm = (uint32_t)((uint64_t)n < cap ? (uint64_t)n : cap);
+    } else if ((uint64_t)n > 0x00FFFFFFull) {
+      fail(L, E_LIST_RANGE, n);
+    } else {
+      rm = (uint32_t)n;
+    }
+    return;
+  }
+}
+
+// Head of the block loop.  Returns true while any lane of the wave still has an item (wave-uniform).
 template <class Src, class Ctx>
 __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& L, const Op& op) {
-  const bool act = L.live && L.err == 0;
   uint32_t& rm = c.remaining(op.c);
-  if (act && rm == 0) {
-    for (;;) {
-      int64_t n = 0;
-      uint32_t e = rd_varint(src, L.cur, L.end, n);
-      if (e) { L.err = e; break; }
-      if (n < 0) {
-        int64_t bsz;
-        e = rd_varint(src, L.cur, L.end, bsz);   // block byte size, ignored
-        if (e) { L.err = e; break; }
-        n = (int64_t)(0 - (uint64_t)n);
-      }
-      if (n == 0) { L.live = false; break; }
-      if (n < 0) continue;                         // i64::MIN negates to itself: `0..n` is empty
-      // Clamp the trip count: with m = min wire bytes per item and R bytes left, no more than R/m
-      // items can decode, so item R/m+1 raises the same error the reference hits.
-      const uint64_t R = L.end - L.cur;
-      if (op.buf2 /*min wire bytes per item*/ > 0) {
-        const uint64_t cap = R / (uint32_t)op.buf2 + 1;
-        rm = (uint32_t)((uint64_t)n < cap ? (uint64_t)n : cap);
-      } else if ((uint64_t)n > 0x00FFFFFFull) {
-        L.err = E_LIST_RANGE; L.edetail = n;
-      } else {
-        rm = (uint32_t)n;
-      }
-      break;
+  const bool need = L.live && rm == 0;            // this lane is at a block boundary
+  // common wire form: a small positive count, or the 0 terminator, in one byte..four bytes
+  const uint64_t x = src.ld5(L.cur);
+  uint32_t raw, n;
+  const bool okv = varint32((uint32_t)x, L.end - L.cur, raw, n);
+  const bool fast = need && okv && (raw & 1u) == 0 && (op.buf2 > 0 || raw == 0);   // non-negative; zero-width items take the exact path
+  const bool slow = need && !fast;
+  if (fast) {
+    const uint32_t cnt = raw >> 1;
+    L.cur += n;
+    if (cnt == 0) L.live = false;
+    else {
+      const uint32_t cap = (L.end - L.cur) / (uint32_t)(op.buf2 > 0 ? op.buf2 : 1) + 1;
+      rm = cnt < cap ? cnt : cap;
     }
   }
-  const bool item = L.live && L.err == 0;
-  if (!__any(item)) return false;
+  if (__any(slow)) {
+    if (slow) list_next_slow(c, src, L, op, rm);
+  }
+  if (!__any(L.live)) return false;
   L.pres = L.live;
   return true;
 }
 
 template <class Ctx>
 __device__ __forceinline__ void h_list_tail(const Ctx& c, Lane& L, const Op& op) {
-  if (L.live && L.err == 0) {
+  if (L.live) {
     c.remaining(op.c) -= 1;
     c.counter(op.a - 1) += 1;     // op.a = child row domain
   }
@@ -464,7 +545,7 @@ __device__ __forceinline__ void h_list_end(const Ctx& c, Lane& L, const Op& op) 
   L.lstk >>= 1;
   L.pres = L.pstk & 1;
   L.pstk >>= 1;
-  if (EMIT && L.live && L.err == 0) {
+  if (EMIT && L.live) {
     // cumulative child rows so far == Arrow offset of the next row (null / empty rows repeat it)
     st_global<uint32_t>(c.buf(op.buf1), (uint64_t)row_of(c, op.dom) + 1, c.gbase(op.a - 1) + c.counter(op.a - 1));
   }

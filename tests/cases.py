@@ -112,6 +112,34 @@ def wire_cases():
         {"i": -1, "l": -1, "f": -1.0, "d": -1.0, "b": True, "s": "é" * 1000},
         {"i": 1, "l": 1, "f": 1.0, "d": 1.0, "b": True, "s": "z" * 70000}])
     out.append(("strings", SCHEMAS["flat_primitives"], recs))
+    # non-canonical (padded) varints everywhere a varint can stand: union branch, string length, int, long,
+    # enum index, block count -- legal for the reference's reader (fast_decode.rs:854-869 accepts any
+    # continuation chain up to 10 bytes); these leave the GPU's single-read fast path.
+    def padded(v: int, width: int) -> bytes:
+        z = (v << 1) ^ (v >> 63)
+        b = bytearray()
+        for i in range(width):
+            b.append((z & 0x7F) | (0x80 if i < width - 1 else 0))
+            z >>= 7
+        assert z == 0
+        return bytes(b)
+    s_nc = json.dumps({"type": "record", "name": "NC", "fields": [
+        {"name": "ns", "type": ["null", "string"]}, {"name": "ni", "type": ["int", "null"]},
+        {"name": "l", "type": "long"}, {"name": "e", "type": {"type": "enum", "name": "E9", "symbols": ["a", "bb", "ccc"]}},
+        {"name": "arr", "type": {"type": "array", "items": "int"}},
+        {"name": "u", "type": ["null", "string", "int"]}, {"name": "b", "type": "boolean"}]})
+    raw = []
+    for w in (1, 2, 3, 5, 9, 10):
+        r = padded(1, w) + padded(3, max(w, 1)) + b"abc"            # ns: branch 1, len 3
+        r += padded(0, w) + padded(-123456 if w >= 3 else 7, max(w, 3))  # ni: branch 0 (int first), value
+        r += padded(2**40 + 5, max(w, 6))                               # l
+        r += padded(2, w)                                               # e -> "ccc"
+        r += padded(2, w) + padded(10, w) + padded(-20, w) + padded(0, w)   # arr: [10, -20]
+        r += padded(2, w) + padded(77, max(w, 2))                             # u: int 77
+        r += b"\x01"
+        raw.append(r)
+    raw.append(b"\x00" + b"\x02" + zigzag(-2**62) + b"\x00" + b"\x00" + b"\x00" + b"\x00")   # nulls / minimal forms
+    out.append(("noncanonical_varints", s_nc, raw))
     return out
 
 
