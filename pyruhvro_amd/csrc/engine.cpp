@@ -48,6 +48,7 @@ struct HipError : std::runtime_error {
 struct DecodeError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic kernels index that far
 
 #define HIPCHK(expr)                                                                          \
   do {                                                                                        \
@@ -469,8 +470,24 @@ struct Events {
   float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
 };
 
+rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
+                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats);
+
 rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats) {
+  try {
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats);
+  } catch (const NeedWideIndex&) {
+    rh_opts o;
+    if (opts) o = *opts;
+    else { o.device = -1; o.stream = nullptr; }
+    o.flags = RH_KERNEL_GENERIC;
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats);
+  }
+}
+
+rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
+                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats) {
   const CompiledSchema& cs = *s->cs;
   int device = 0;
   if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
@@ -501,7 +518,9 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   // kernel form: schema-specialised (compiled once per schema, cached) or the generic interpreter
   const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
   const SpecKernel* sk = nullptr;
-  if (mode != RH_KERNEL_GENERIC && n > 0) {
+  // the specialised kernels address every chunk buffer with 32-bit byte offsets
+  const bool narrow_ok = std::max(r.sz, r.rows_last) < (1ull << 28);
+  if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
     const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
     const SpecKernel& k0 = spec_kernel(s, device, may_compile);
     if (k0.ok) sk = &k0;
@@ -542,7 +561,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   win = std::max<uint64_t>(win, 8192);
   const uint64_t lds_cap = 160 * 1024 - 512;
   if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
-  win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) * 5 / 9 & ~15ull, 80 * 1024));   // leave room for string staging
+  win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
   P.win_bytes = (uint32_t)win;
   const uint32_t lds_bytes = lds_fixed + (uint32_t)win;   // k_size; k_emit adds the string staging area
 
@@ -594,6 +613,10 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   r.data_bytes = totals;
   for (auto t : totals)
     if (t > 0x7FFFFFFFull) throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
+  if (sk)
+    for (int d = 1; d < cs.ndom; d++)
+      for (uint32_t c = 0; c < k; c++)
+        if (totals[(size_t)(d - 1) * k + c] >= (1ull << 28)) throw NeedWideIndex();
   r.buf_off.assign((size_t)nbuf * k, 0);
   r.buf_size.assign((size_t)nbuf * k, 0);
   uint64_t off = 0, exact = 0;
@@ -639,25 +662,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   ev.rec(3, stream);
   uint32_t emit_lds = 0;
   if (n > 0) {
-    // string staging area: mean string bytes of 256 records + 25 %, one 16-byte phase slot per column
-    uint64_t str_total = 0;
-    int nstr = 0;
-    for (int kk = cs.ndom - 1; kk < K; kk++) {
-      nstr++;
-      for (uint32_t c = 0; c < k; c++) str_total += totals[(size_t)kk * k + c];
-    }
-    uint64_t stage = nstr ? align_up(str_total * rh::kBlock / n * 5 / 4 + 32ull * nstr + 1024, 16) : 0;
-    const uint64_t room = lds_cap > lds_bytes ? (lds_cap - lds_bytes) & ~15ull : 0;
-    if (stage > room) stage = room;
-    if (stage < 32ull * nstr + 256) stage = 0;
-    // Measured on MI355X (full schema, 10M records): staging string bytes in LDS and flushing them with
-    // aligned 16-byte stores costs more in occupancy (70 KB vs 38 KB of LDS per workgroup, 2 vs 4 workgroups
-    // per CU) than the per-lane 8-byte unaligned stores cost in HBM efficiency (3.0 ms vs 1.8 ms), so the
-    // direct path is the default; RUHVRO_HIP_STAGE=1 turns the staging path back on.
-    static const bool use_stage = [] { const char* e = std::getenv("RUHVRO_HIP_STAGE"); return e && *e == '1'; }();
-    if (!use_stage) stage = 0;
-    P.stage_bytes = (uint32_t)stage;
-    emit_lds = lds_bytes + (uint32_t)stage;
+    emit_lds = lds_bytes;
     if (sk ? launch_module(sk->emit_fn, P, nblocks, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
       throw HipError("k_emit launch failed");
   }

@@ -33,6 +33,15 @@ __device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
   return g;
 }
 
+// XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md), and
+// each XCD has its own L2.  Neighbouring tiles write neighbouring bytes of every output buffer (a validity
+// bitmap advances 32 bytes per tile), so giving each XCD one CONTIGUOUS run of tiles lets its L2 merge those
+// partial lines instead of eight L2s each owning a sliver.  Pure performance mapping: any placement is correct.
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) {
+  const uint32_t per = nblocks >> 3;
+  return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+}
+
 // Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction).
 // The loads of a batch of 8 vectors per thread are ALL issued before the first LDS store, so a
 // workgroup pays one HBM round trip per 32 KiB of window instead of one per 4 KiB.
@@ -89,28 +98,14 @@ __device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& 
 // Lowest erroring lane of the workgroup reports (code, detail); lowest record index wins globally
 // (== the in-order join of deserialize.rs:115-119 + first `?` in fast_decode.rs:827).
 // Contains a workgroup barrier.
-__device__ __forceinline__ void report_errors(const KParams& P, uint32_t* misc, const Lane& L, const Geo& g, uint32_t tid) {
+__device__ __forceinline__ void report_errors(const KParams& P, uint32_t* misc, const Lane& L, const Geo& g, uint32_t tid, uint32_t tile) {
   if (L.err) atomicMin(&misc[0], tid);
   __syncthreads();
   if (misc[0] == tid) {
     ErrInfo ei; ei.code = L.err; ei.pad = 0; ei.detail = L.edetail;
-    P.errinfo[blockIdx.x] = ei;
+    P.errinfo[tile] = ei;
     atomicMax(P.first_bad, ~(unsigned long long)(g.rec0 + tid));
   }
-}
-
-// One wave copies T staged bytes (LDS, same 16-byte phase as the destination) to HBM address `ga`:
-// <= 15 head bytes, aligned 16-byte vectors (1 KiB per instruction), <= 15 tail bytes.
-__device__ __forceinline__ void flush_column(uint64_t ga, const uint8_t* sp, uint32_t T, uint32_t lane) {
-  RH_GLOBAL uint8_t* gp = reinterpret_cast<RH_GLOBAL uint8_t*>(ga);
-  uint32_t head = (16u - (uint32_t)(ga & 15)) & 15u;
-  if (head > T) head = T;
-  if (lane < head) gp[lane] = sp[lane];
-  const uint32_t body = T - head, nvec = body >> 4, tail = body & 15;
-  RH_GLOBAL v4u* gv = reinterpret_cast<RH_GLOBAL v4u*>(ga + head);
-  const v4u* sv = reinterpret_cast<const v4u*>(sp + head);
-  for (uint32_t i = lane; i < nvec; i += 64) gv[i] = sv[i];
-  if (lane < tail) gp[head + (nvec << 4) + lane] = sp[head + (nvec << 4) + lane];
 }
 
 }  // namespace rh

@@ -17,11 +17,8 @@
 //   k_emit  recomputes the counters of its 256 records, scans them inside the
 //           workgroup, then walk 2 writes every Arrow buffer: values and
 //           offsets at [row] (coalesced), validity / boolean bitmaps with one
-//           64-bit ballot store per wavefront, sparse-union type ids.  String
-//           bytes are gathered per column into an LDS staging area laid out
-//           with the destination's 16-byte phase, and flushed to HBM with
-//           aligned 16-byte stores (one wave per column, 1 KiB per
-//           instruction) -- no per-lane byte stores to HBM.
+//           64-bit ballot store per wavefront, sparse-union type ids, string
+//           bytes with per-lane 8-byte stores at the scanned byte offsets.
 // HBM-bound byte shuffling: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,13 +33,12 @@ namespace rh {
 // interpreter context: per-lane counters live in LDS ([id][256], conflict-free)
 // --------------------------------------------------------------------------
 struct ICtx {
+  static constexpr bool kWide = true;   // 64-bit buffer indexing: any chunk size
   uint32_t* cnt;             // LDS [K][256]
   uint32_t* rem;             // LDS [depth][256]
   uint32_t* nullcnt;         // LDS [nnodes]
   const uint64_t* bufs;      // LDS [nbuf]   this chunk's buffer addresses
   const uint32_t* gb;        // LDS [K]      chunk-relative base of this workgroup per counter
-  const uint32_t* so;        // LDS [K]      staging offset per string counter
-  uint8_t* stg;              // LDS staging area
   const uint32_t* sym_off;
   const uint8_t* sym_data;
   uint32_t lrow;             // chunk-local row of this lane (domain 0)
@@ -53,8 +49,6 @@ struct ICtx {
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d * kBlock + tid]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
-  __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
-  __device__ __forceinline__ uint8_t* stage() const { return stg; }
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
   }
@@ -102,20 +96,17 @@ struct Smem {
   uint32_t* cnt;      // [K][256]
   uint32_t* rem;      // [list_depth][256]
   uint32_t* wtot;     // [K][4]
-  uint32_t* tot;      // [K]   workgroup totals
   uint32_t* gb;       // [K]   chunk-relative workgroup base
-  uint32_t* so;       // [K]   staging offsets
   uint32_t* nullcnt;  // [nnodes]
   uint32_t* misc;     // [4]: 0 = lowest erroring tid
   uint64_t* bufs;     // [nbuf]
   uint8_t* win;       // input window (16-byte aligned, +16 bytes of slack)
-  uint8_t* stage;     // string staging (16-byte aligned)
 };
 
 __host__ __device__ inline uint32_t lds_fixed_words(int K, int list_depth, int nnodes, int nbuf) {
   const uint32_t k1 = (uint32_t)(K > 0 ? K : 1);
   const uint32_t k4 = (k1 + 3) & ~3u;
-  return k1 * kBlock + (uint32_t)(list_depth > 0 ? list_depth : 1) * kBlock + k1 * 4 + 3 * k4 +
+  return k1 * kBlock + (uint32_t)(list_depth > 0 ? list_depth : 1) * kBlock + k1 * 4 + k4 +
          (uint32_t)((nnodes + 3) & ~3) + 4 + 2 * (uint32_t)((nbuf + 1) & ~1);
 }
 
@@ -127,14 +118,11 @@ __device__ __forceinline__ Smem carve(const KParams& P, uint8_t* smem) {
   s.cnt = p; p += k1 * kBlock;
   s.rem = p; p += (P.list_depth > 0 ? P.list_depth : 1) * kBlock;
   s.wtot = p; p += k1 * 4;
-  s.tot = p; p += k4;
   s.gb = p; p += k4;
-  s.so = p; p += k4;
   s.nullcnt = p; p += ((P.nnodes + 3) & ~3);
   s.misc = p; p += 4;
   s.bufs = reinterpret_cast<uint64_t*>(p); p += 2 * ((P.nbuf + 1) & ~1);
   s.win = reinterpret_cast<uint8_t*>(p);          // all pieces above are multiples of 16 bytes
-  s.stage = s.win + P.win_bytes + 16;
   return s;
 }
 
@@ -156,7 +144,7 @@ __device__ __forceinline__ void run_walk(const KParams& P, const ICtx& c, const 
 
 __device__ __forceinline__ ICtx make_ctx(const KParams& P, const Smem& s, const Geo& g, uint32_t tid) {
   ICtx c;
-  c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.bufs = s.bufs; c.gb = s.gb; c.so = s.so; c.stg = s.stage;
+  c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.bufs = s.bufs; c.gb = s.gb;
   c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.tid = tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
   return c;
@@ -188,7 +176,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) {
     uint32_t v = wave_sum(s.cnt[k * kBlock + tid]);
     if (lane == 0) s.wtot[k * 4 + wave] = v;
   }
-  report_errors(P, s.misc, L, g, tid);   // contains the barrier that publishes wtot
+  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot
   if ((int)tid < P.K)
     P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
@@ -277,26 +265,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
       for (uint32_t w = 0; w < wave; w++) base += s.wtot[k * 4 + w];
       s.cnt[k * kBlock + tid] += base;             // workgroup-local exclusive prefix
     }
-    if ((int)tid < P.K) {
-      s.tot[tid] = s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
-      s.gb[tid] = P.blockbase[(size_t)tid * P.nblocks + blockIdx.x];
-    }
-    __syncthreads();
-    // staging layout: column k's bytes start at stage + so[k], with so[k] == HBM destination (mod 16)
-    if (tid == 0) {
-      uint32_t off = 0;
-      bool ok = P.stage_bytes > 0;
-      for (int k = P.ndom - 1; k < P.K && ok; k++) {
-        const uint64_t G = s.bufs[P.cnt_databuf[k]] + s.gb[k];
-        const uint32_t mis = (uint32_t)(G & 15);
-        s.so[k] = off + mis;
-        off += (mis + s.tot[k] + 15) & ~15u;
-        if (off > P.stage_bytes) ok = false;
-      }
-      if (!ok)
-        for (int k = 0; k < P.K; k++) s.so[k] = kNoStage;
-      s.misc[1] = ok ? 1u : 0u;
-    }
+    if ((int)tid < P.K) s.gb[tid] = P.blockbase[(size_t)tid * P.nblocks + blockIdx.x];
     __syncthreads();
   }
 
@@ -304,19 +273,10 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
   run_walk<true>(P, c, s, L, fits, wb16);
 
-  report_errors(P, s.misc, L, g, tid);   // barrier inside: nullcnt + staging complete
+  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // barrier inside: nullcnt + staging complete
   for (int i = tid; i < P.nnodes; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
-  }
-
-  // flush the staged string bytes: one wave per column, aligned 16-byte stores
-  if (P.K > 0 && s.misc[1]) {
-    for (int k = P.ndom - 1 + (int)wave; k < P.K; k += 4) {
-      const uint32_t T = s.tot[k];
-      if (T == 0) continue;
-      flush_column(s.bufs[P.cnt_databuf[k]] + s.gb[k], s.stage + s.so[k], T, lane);
-    }
   }
 }
 

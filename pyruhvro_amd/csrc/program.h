@@ -97,7 +97,6 @@ struct KParams {
   uint32_t bpc;              // workgroups per (non-last) chunk
   uint32_t nblocks;
   uint32_t win_bytes;        // LDS bytes reserved for the input window
-  uint32_t stage_bytes;      // LDS bytes reserved for staging string bytes (k_emit; 0 = write HBM directly)
 
   const Op* prog;
   const uint32_t* sym_off;

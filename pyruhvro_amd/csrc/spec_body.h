@@ -58,14 +58,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <class S>
 struct SCtx {
   static constexpr int K1 = S::K > 0 ? S::K : 1;
+  static constexpr bool kWide = false;   // 32-bit byte offsets into each buffer (host guards: buffers < 4 GiB per chunk)
   mutable uint32_t cnt[K1];                           // per-lane counters (registers)
   mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
   uint64_t bufs[S::NBUF > 0 ? S::NBUF : 1];           // this chunk's Arrow buffer addresses (uniform)
   uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
-  uint32_t so[K1];                                    // LDS staging offset per string counter
   mutable uint32_t nacc[S::NNODES];                   // nulls seen by this wave per node (wave-uniform)
   uint32_t* nullcnt;                                  // LDS [NNODES]
-  uint8_t* stg;                                       // LDS staging area
   const uint32_t* sym_off;
   const uint8_t* sym_data;
   uint32_t lrow, lane;
@@ -75,8 +74,6 @@ struct SCtx {
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
-  __device__ __forceinline__ uint32_t stage_off(int id) const { return so[id]; }
-  __device__ __forceinline__ uint8_t* stage() const { return stg; }
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { nacc[node] += n; }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
@@ -92,14 +89,12 @@ struct SpecSmem {
   uint32_t* nullcnt;
   uint32_t* misc;
   uint8_t* win;
-  uint8_t* stage;
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
     wtot = p; p += (S::K > 0 ? S::K : 1) * 4;
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
     misc = p; p += 4;
     win = reinterpret_cast<uint8_t*>(p);
-    stage = win + P.win_bytes + 16;
   }
 };
 
@@ -116,10 +111,10 @@ __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c
 
 template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
-  static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; c.so[k] = kNoStage; });
+  static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
   static_for<0, S::NNODES>([&](auto in) { c.nacc[decltype(in)::value] = 0; });
-  c.nullcnt = s.nullcnt; c.stg = s.stage; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
+  c.nullcnt = s.nullcnt; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
 }
 
@@ -132,7 +127,8 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
-  const Geo g = geometry(P, blockIdx.x);
+  const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
+  const Geo g = geometry(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
@@ -157,16 +153,16 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     const uint32_t v = wave_sum(c.cnt[k]);
     if (lane == 0) s.wtot[k * 4 + wave] = v;
   });
-  report_errors(P, s.misc, L, g, tid);   // contains the barrier that publishes wtot
+  report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot
   if ((int)tid < S::K)
-    P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
+    P.blocksum[(size_t)tid * P.nblocks + tile] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
   RH_MARK(19);
   RH_MARK_FLUSH;
 }
 
 // --------------------------------------------------------------------------
-// emit pass: re-size, scan inside the workgroup, materialise, flush staged strings
+// emit pass: re-size, scan inside the workgroup, materialise
 // --------------------------------------------------------------------------
 template <class S>
 __device__ __forceinline__ void spec_emit(const KParams& P) {
@@ -174,7 +170,8 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
-  const Geo g = geometry(P, blockIdx.x);
+  const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
+  const Geo g = geometry(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
@@ -188,7 +185,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   });
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
-    c.gb[k] = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
+    c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
@@ -199,8 +196,6 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   __syncthreads();
   RH_MARK(1);
 
-  uint32_t tot[SCtx<S>::K1];
-  bool staged = false;
   if (S::K > 0) {
     lane_init_from(L, g, o0, o1, wb16, tid);
     RH_MARK(2);
@@ -216,23 +211,11 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     RH_MARK(4);
     __syncthreads();
     RH_MARK(5);
-    // every lane derives the (uniform) workgroup totals, bases and staging layout itself: no second barrier
-    uint32_t off = 0;
-    staged = P.stage_bytes > 0;
-    static_for<0, S::K>([&](auto ik) {
+    static_for<0, S::K>([&](auto ik) {   // workgroup-local exclusive prefix
       constexpr int k = decltype(ik)::value;
-      const uint32_t w0 = s.wtot[k * 4], w1 = s.wtot[k * 4 + 1], w2 = s.wtot[k * 4 + 2], w3 = s.wtot[k * 4 + 3];
-      c.cnt[k] += (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);   // workgroup-local exclusive prefix
-      tot[k] = w0 + w1 + w2 + w3;
-      if constexpr (k >= S::NDOM - 1) {   // string byte column: staging slot with the destination's 16-byte phase
-        const uint64_t G = c.bufs[S::databuf(k)] + c.gb[k];
-        const uint32_t mis = (uint32_t)(G & 15);
-        c.so[k] = off + mis;
-        off += (mis + tot[k] + 15) & ~15u;
-      }
+      const uint32_t w0 = s.wtot[k * 4], w1 = s.wtot[k * 4 + 1], w2 = s.wtot[k * 4 + 2];
+      c.cnt[k] += (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
     });
-    if (off > P.stage_bytes) staged = false;
-    if (!staged) static_for<0, S::K>([&](auto ik) { c.so[decltype(ik)::value] = kNoStage; });
   }
 
   RH_MARK(6);
@@ -246,21 +229,13 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       if (c.nacc[i]) atomicAdd(&s.nullcnt[i], c.nacc[i]);
     });
 
-  report_errors(P, s.misc, L, g, tid);   // barrier inside: nullcnt + staging complete
+  report_errors(P, s.misc, L, g, tid, tile);   // barrier inside: nullcnt + staging complete
   RH_MARK(8);
   for (int i = tid; i < S::NNODES; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
   }
 
-  // flush the staged string bytes: one wave per column, aligned 16-byte stores
-  if (S::K > 0 && staged) {
-    static_for<S::NDOM - 1, S::K>([&](auto ik) {
-      constexpr int k = decltype(ik)::value;
-      if (((k - (S::NDOM - 1)) & 3) == (int)wave && tot[k] != 0)
-        flush_column(c.bufs[S::databuf(k)] + c.gb[k], s.stage + c.so[k], tot[k], lane);
-    });
-  }
   RH_MARK(9);
   RH_MARK_FLUSH;
 }

@@ -32,19 +32,21 @@ typedef uint16_t __attribute__((aligned(1))) u16u;
 // --------------------------------------------------------------------------
 // wave primitives (wave = 64 lanes)
 // --------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= (uint32_t)d) v += t;
-  }
+// Inclusive wave scan in the VALU with DPP (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast
+// 15 and 31 across rows): six v_add with DPP modifiers, no LDS-crossbar (ds_bpermute) round trips.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
   return v;
 }
 
+// wave total, returned wave-uniform (SGPR)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
 
 // --------------------------------------------------------------------------
@@ -96,9 +98,17 @@ struct GlobalSrc {
 // Arrow buffers live in HBM: typed global-address-space accessors keep the compiler from emitting
 // flat_* instructions (which tie up both the vector-memory and the LDS counters).
 #define RH_GLOBAL __attribute__((address_space(1)))
-template <class T>
-__device__ __forceinline__ void st_global(void* base, uint64_t idx, T v) {
-  reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base))[idx] = v;
+// WIDE = false: the byte offset idx * sizeof(T) is formed in 32 bits, so the store takes the
+// uniform-base + 32-bit-lane-offset addressing form (no 64-bit address arithmetic per lane).  The host
+// only launches kernels built that way when every buffer of a chunk is smaller than 4 GiB.
+template <class T, bool WIDE>
+__device__ __forceinline__ void st_global(void* base, uint32_t idx, T v) {
+  if (WIDE) {
+    reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base))[(uint64_t)idx] = v;
+  } else {
+    const uint32_t boff = idx * (uint32_t)sizeof(T);
+    *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + boff) = v;
+  }
 }
 __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint32_t bits) {
   __hip_atomic_fetch_or(reinterpret_cast<RH_GLOBAL uint32_t*>(reinterpret_cast<uintptr_t>(base)) + idx, bits,
@@ -116,11 +126,7 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
     if (len & 1) *reinterpret_cast<P8>(d + j) = (uint8_t)x;                      \
   }
 
-template <class Src>   // d in LDS (string staging area)
-__device__ __forceinline__ void copy_bytes(uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
-  RH_COPY_BODY(u64u*, u32u*, u16u*, uint8_t*)
-}
-template <class Src>   // d in HBM (unstaged fallback)
+template <class Src>
 __device__ __forceinline__ void copy_bytes(RH_GLOBAL uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
   RH_COPY_BODY(RH_GLOBAL u64u*, RH_GLOBAL u32u*, RH_GLOBAL u16u*, RH_GLOBAL uint8_t*)
 }
@@ -278,14 +284,10 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
 //   uint32_t& remaining(int d)  items left in the current block of list depth d
 //   void* buf(int id)           this chunk's Arrow buffer `id`
 //   uint32_t gbase(int id)      chunk-relative base of this workgroup for counter id
-//   uint32_t stage_off(int id)  LDS staging offset of string counter id (kNoStage = write to HBM directly)
-//   uint8_t* stage()            LDS staging area
 //   void add_nulls_wave(int node, uint32_t n)   n is wave-uniform (called by every lane)
 //   void add_nulls_lane(int node)               one null row of this lane (child domains)
 //   lrow, lane, wave_live, sym_off, sym_data
 // --------------------------------------------------------------------------
-constexpr uint32_t kNoStage = 0xFFFFFFFFu;
-
 template <class Ctx>
 __device__ __forceinline__ uint32_t row_of(const Ctx& c, int dom) {
   return dom == 0 ? c.lrow : c.gbase(dom - 1) + c.counter(dom - 1);
@@ -299,7 +301,7 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
   if (op.dom == 0) {   // rows == lanes: one ballot, one 64-bit store per wavefront
     const uint64_t m = __ballot(valid);
     const uint64_t nm = __ballot(act && !valid);
-    if (c.lane == 0 && c.wave_live) st_global<uint64_t>(c.buf(op.buf0), c.lrow >> 6, m);
+    if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf0), c.lrow >> 6, m);
     c.add_nulls_wave(op.node, (uint32_t)__popcll(nm));
   } else if (act) {
     if (valid) atomic_or_global(c.buf(op.buf0), row >> 5, 1u << (row & 31));
@@ -346,13 +348,13 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     if (op.a == FK_BOOL) {
       if (op.dom == 0) {
         const uint64_t m = __ballot(bits != 0);
-        if (c.lane == 0 && c.wave_live) st_global<uint64_t>(c.buf(op.buf1), c.lrow >> 6, m);
+        if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf1), c.lrow >> 6, m);
       } else if (act && bits) {
         atomic_or_global(c.buf(op.buf1), row >> 5, 1u << (row & 31));
       }
     } else if (act) {
-      if (op.a == FK_I32 || op.a == FK_F32) st_global<uint32_t>(c.buf(op.buf1), row, (uint32_t)bits);
-      else st_global<uint64_t>(c.buf(op.buf1), row, bits);
+      if (op.a == FK_I32 || op.a == FK_F32) st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row, (uint32_t)bits);
+      else st_global<uint64_t, Ctx::kWide>(c.buf(op.buf1), row, bits);
     }
   }
   put_validity<EMIT>(c, op, act, valid, row);
@@ -395,18 +397,15 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
     row = row_of(c, op.dom);
     if (act) {
       const uint32_t gb = c.gbase(op.a);
-      st_global<uint32_t>(c.buf(op.buf1), (uint64_t)row + 1, gb + o + len);   // offsets repeat under nulls
+      st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row + 1, gb + o + len);   // offsets repeat under nulls
       if (len) {
-        const uint32_t so = c.stage_off(op.a);
-        if (so != kNoStage) {
-          uint8_t* d = c.stage() + so + o;
-          if (op.code == OP_STRING) copy_bytes(d, src, spos, len);
-          else copy_plain(d, c.sym_data + spos, len);
-        } else {
-          RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
-          if (op.code == OP_STRING) copy_bytes(d, src, spos, len);
-          else copy_plain(d, c.sym_data + spos, len);
-        }
+        // String bytes go straight to HBM with per-lane 8-byte stores at any alignment: neighbouring lanes
+        // own neighbouring rows, so one wave store covers one contiguous span of the column.  (Staging the
+        // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
+        // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
+        RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
+        if (op.code == OP_STRING) copy_bytes(d, src, spos, len);
+        else copy_plain(d, c.sym_data + spos, len);
       }
     }
   }
@@ -446,7 +445,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   }
   uint32_t tidv = 0;
   if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
-  if (EMIT && act) st_global<int8_t>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
+  if (EMIT && act) st_global<int8_t, Ctx::kWide>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
 }
 __device__ __forceinline__ void h_variant(Lane& L, const Op& op) {
   L.pres = (L.pstk & 1) && ((uint32_t)(L.sstk & 0xFF) == (uint32_t)op.a);
@@ -547,7 +546,7 @@ __device__ __forceinline__ void h_list_end(const Ctx& c, Lane& L, const Op& op) 
   L.pstk >>= 1;
   if (EMIT && L.live) {
     // cumulative child rows so far == Arrow offset of the next row (null / empty rows repeat it)
-    st_global<uint32_t>(c.buf(op.buf1), (uint64_t)row_of(c, op.dom) + 1, c.gbase(op.a - 1) + c.counter(op.a - 1));
+    st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row_of(c, op.dom) + 1, c.gbase(op.a - 1) + c.counter(op.a - 1));
   }
 }
 
