@@ -53,6 +53,17 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/hbm_traffic.json, written by scripts/rocpd_summary.py --traffic-json from separate
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        return float(d[kernel]["hbm_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int):
     """Oracle C walker with the reference's threading shape, bounded sample, best of 3."""
     from avrogen import fastgen
@@ -178,6 +189,7 @@ def main(argv=None):
     emit_ms = agg["emit_kernel_ms_max"]
     achieved = alg_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
     path_ms = r0["size_kernel_ms"] + r0["scan_kernel_ms"] + r0["emit_kernel_ms"]
+    emit_kernel = "rh_spec_emit" if getattr(run, "info", {}).get("specialized") else "rh_k_emit"
     out = {
         "metric": "Avro records/sec -> Arrow (direct decode, input and output resident in HBM)",
         "value": agg["records_per_s"],
@@ -199,8 +211,9 @@ def main(argv=None):
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
                    "path_kernel_ms": path_ms,
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
-        "roofline": {"bound": "hbm", "kernel": "rh_k_emit", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": emit_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": measured_traffic(emit_kernel) if args.workload == "full10m" else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "bytes_per_record": alg_bytes / n, "avg_launch_ms": emit_ms},
     }
