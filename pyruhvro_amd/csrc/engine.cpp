@@ -534,7 +534,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint64_t o_err = ctrl_bytes;
   const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
   const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
-  const uint64_t ws_bytes = align_up(o_bbase + 4ull * K * nblocks, kAlign);
+  const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
+  const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
+  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 2ull * K * nblocks * rh::kBlock : 0), kAlign);
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
   HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
@@ -552,6 +554,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
   P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
   P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
+  P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
+  P.lanecnt = (uint16_t*)(ws.ptr() + o_lcnt);
 
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)

@@ -116,6 +116,9 @@ struct KParams {
   ErrInfo* errinfo;          // [nblocks]
   void* const* bufptr;       // [k][nbuf]
   uint32_t* nullcount;       // [nnodes][k]
+  // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
+  uint16_t* lanecnt;         // [K][nblocks*256] per-record counters, saturated at 0xFFFF
+  uint32_t* tileflag;        // [nblocks] 1 = a counter of this tile saturated: k_emit re-runs the size walk
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
 };
 

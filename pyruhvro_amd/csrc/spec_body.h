@@ -135,7 +135,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   if (fits) stage_window(P, s.win, wb16, we, tid);
-  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
+  if (tid == 0) { s.misc[0] = 0xFFFFFFFFu; s.misc[2] = 0; }
   __syncthreads();
   RH_MARK(16);
 
@@ -148,12 +148,19 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
   RH_MARK(18);
 
+  // per-record counters -> HBM (2 bytes each, coalesced per counter) so that k_emit can skip its size walk
+  bool sat = false;
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
-    const uint32_t v = wave_sum(c.cnt[k]);
+    const uint32_t cv = c.cnt[k];
+    sat |= cv > 0xFFFFu;
+    st_global<uint16_t, false>(P.lanecnt + (size_t)k * ((size_t)P.nblocks * kBlock), tile * kBlock + tid, (uint16_t)(cv > 0xFFFFu ? 0xFFFFu : cv));
+    const uint32_t v = wave_sum(cv);
     if (lane == 0) s.wtot[k * 4 + wave] = v;
   });
-  report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot
+  if (S::K > 0 && __any(sat) && lane == 0) atomicOr(&s.misc[2], 1u);
+  report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
+  if (S::K > 0 && tid == 0) P.tileflag[tile] = s.misc[2];
   if ((int)tid < S::K)
     P.blocksum[(size_t)tid * P.nblocks + tile] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
@@ -187,6 +194,15 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     constexpr int k = decltype(ik)::value;
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
+  // this record's counters as k_size left them (requested with the window, so no extra round trip)
+  uint32_t rewalk = 0;
+  if (S::K > 0) {
+    rewalk = P.tileflag[tile];
+    static_for<0, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      c.cnt[k] = (P.lanecnt + (size_t)k * ((size_t)P.nblocks * kBlock))[tile * kBlock + tid];
+    });
+  }
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);
@@ -197,9 +213,11 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(1);
 
   if (S::K > 0) {
-    lane_init_from(L, g, o0, o1, wb16, tid);
-    RH_MARK(2);
-    spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+    if (rewalk) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
+      static_for<0, S::K>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
+      lane_init_from(L, g, o0, o1, wb16, tid);
+      spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+    }
     RH_MARK(3);
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;

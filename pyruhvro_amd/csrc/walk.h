@@ -101,8 +101,12 @@ struct GlobalSrc {
 // WIDE = false: the byte offset idx * sizeof(T) is formed in 32 bits, so the store takes the
 // uniform-base + 32-bit-lane-offset addressing form (no 64-bit address arithmetic per lane).  The host
 // only launches kernels built that way when every buffer of a chunk is smaller than 4 GiB.
+#ifndef RH_EXP
+#define RH_EXP 0
+#endif
 template <class T, bool WIDE>
 __device__ __forceinline__ void st_global(void* base, uint32_t idx, T v) {
+  if (RH_EXP == 2) return;
   if (WIDE) {
     reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base))[(uint64_t)idx] = v;
   } else {
@@ -115,22 +119,40 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// copy `len` bytes window[sp..] -> d, any alignment on both sides: 8 bytes per DS / global instruction.
-#define RH_COPY_BODY(P64, P32, P16, P8)                                         \
-  uint32_t j = 0;                                                                \
-  for (; j + 8 <= len; j += 8) *reinterpret_cast<P64>(d + j) = s.ld8(sp + j);    \
-  if (len & 7) {                                                                 \
-    uint64_t x = s.ld8(sp + j);                                                  \
-    if (len & 4) { *reinterpret_cast<P32>(d + j) = (uint32_t)x; x >>= 32; j += 4; } \
-    if (len & 2) { *reinterpret_cast<P16>(d + j) = (uint16_t)x; x >>= 16; j += 2; } \
-    if (len & 1) *reinterpret_cast<P8>(d + j) = (uint8_t)x;                      \
-  }
-
+// copy `len` bytes window[sp..] -> d (HBM), any alignment on both sides, with at most TWO store
+// instructions per 16 bytes: the tail of a string is written as the LAST 8 (4, 2) bytes ending at its end,
+// overlapping what the first store already wrote, instead of 4+2+1-byte pieces.  (Unaligned per-lane stores
+// cost ~44 TA cycles per wave instruction on MI355X whatever their width -- tools/gmemalign.hip -- so the
+// instruction count is what matters.)  Both window reads of a round are issued before the first store.
 template <class Src>
 __device__ __forceinline__ void copy_bytes(RH_GLOBAL uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
-  RH_COPY_BODY(RH_GLOBAL u64u*, RH_GLOBAL u32u*, RH_GLOBAL u16u*, RH_GLOBAL uint8_t*)
+  if (RH_EXP == 1 || RH_EXP == 2) return;
+  if (len >= 8) {
+    uint32_t j = 0;
+    for (; j + 16 <= len; j += 16) {
+      const uint64_t x0 = s.ld8(sp + j), x1 = s.ld8(sp + j + 8);
+      *reinterpret_cast<RH_GLOBAL u64u*>(d + j) = x0;
+      *reinterpret_cast<RH_GLOBAL u64u*>(d + j + 8) = x1;
+    }
+    if (j < len) {   // 1..15 bytes left, and at least 8 bytes precede the end: [j, j+8) if it fits, then the last 8
+      const uint32_t a = j + 8 <= len ? j : len - 8;
+      const uint64_t x0 = s.ld8(sp + a), x1 = s.ld8(sp + len - 8);
+      *reinterpret_cast<RH_GLOBAL u64u*>(d + a) = x0;
+      if (j + 8 < len) *reinterpret_cast<RH_GLOBAL u64u*>(d + len - 8) = x1;
+    }
+  } else {
+    const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
+    if (len >= 4) {
+      *reinterpret_cast<RH_GLOBAL u32u*>(d) = (uint32_t)x;
+      if (len > 4) *reinterpret_cast<RH_GLOBAL u32u*>(d + len - 4) = (uint32_t)(x >> (8 * (len - 4)));
+    } else if (len >= 2) {
+      *reinterpret_cast<RH_GLOBAL u16u*>(d) = (uint16_t)x;
+      if (len > 2) d[2] = (uint8_t)(x >> 16);
+    } else {
+      d[0] = (uint8_t)x;
+    }
+  }
 }
-#undef RH_COPY_BODY
 
 template <class D>
 __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len) {
