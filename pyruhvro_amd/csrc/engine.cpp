@@ -311,9 +311,16 @@ namespace {
 // ---------------------------------------------------------------------------
 // Arrow C Data export
 // ---------------------------------------------------------------------------
-struct Slab {   // host copy of the arena, shared by the k chunk arrays
+struct Slab {   // host copy of the arena, shared by the k chunk arrays (freed when the last one is released)
   std::atomic<int> refs{0};
   void* base = nullptr;
+  Block pinned;           // large results live in pooled pinned memory: the D2H copy runs at PCIe speed
+  void free_mem() {
+    if (pinned.p) pin_pool().put(pinned);
+    else std::free(base);
+    pinned = Block();
+    base = nullptr;
+  }
 };
 
 struct ArrayPriv {
@@ -330,7 +337,7 @@ void release_array(ArrowArray* a) {
     delete c;
   }
   if (p->slab && p->slab->refs.fetch_sub(1) == 1) {
-    std::free(p->slab->base);
+    p->slab->free_mem();
     delete p->slab;
   }
   delete p;
@@ -707,12 +714,23 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
 int to_host_impl(rh_device_result* r, ArrowArray* out_chunks) {
   Slab* slab = new Slab();
-  if (posix_memalign(&slab->base, 64, r->arena_bytes) != 0) { delete slab; throw std::bad_alloc(); }
-  hipError_t e = hipMemcpy(slab->base, r->arena.ptr(), r->arena_bytes, hipMemcpyDeviceToHost);
-  if (e != hipSuccess) { std::free(slab->base); delete slab; throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e)); }
+  try {
+    if (r->arena_bytes >= (1ull << 20)) {
+      slab->pinned = pin_pool().get(r->arena_bytes, r->device);
+      slab->base = slab->pinned.p;
+    } else if (posix_memalign(&slab->base, 64, r->arena_bytes) != 0) {
+      throw std::bad_alloc();
+    }
+    hipError_t e = hipMemcpy(slab->base, r->arena.ptr(), r->arena_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e));
+  } catch (...) {
+    slab->free_mem();
+    delete slab;
+    throw;
+  }
   slab->refs.store(1);   // guard while building
   for (uint32_t c = 0; c < r->k; c++) export_chunk(*r, c, (const uint8_t*)slab->base, slab, &out_chunks[c]);
-  if (slab->refs.fetch_sub(1) == 1) { std::free(slab->base); delete slab; }
+  if (slab->refs.fetch_sub(1) == 1) { slab->free_mem(); delete slab; }
   return 0;
 }
 
