@@ -114,6 +114,16 @@ def test_generated_records(name, n, k):
     _check(synth.records(name, n, seed=3), SCHEMAS[name], k)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_schemas_and_records(seed, kernel):
+    """Seeded random schemas inside the direct-decode subset x random records (tests/random_cases.py)."""
+    import random_cases
+    if kernel == cabi.KERNEL_SPECIALIZED and seed >= 6:
+        pytest.skip("specialised kernels: 6 random schemas (each is a run-time hiprtc compile)")
+    js, recs = random_cases.random_case(seed, 700)
+    _check(recs, js, 1 + seed % 4)
+
+
 def test_chunk_semantics():
     recs = synth.records("full", 103)
     for k, want in ((1, [103]), (8, [12] * 7 + [19]), (0, [103]), (103, [1] * 103), (500, [1] * 103), (2, [51, 52])):

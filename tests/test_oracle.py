@@ -161,6 +161,18 @@ def test_walkers_agree_on_generated(name):
     assert _norm(a.to_pylist()) == _norm(exp)                          # end-to-end known answer
 
 
+@pytest.mark.parametrize("seed", range(0, 40, 4))
+def test_walkers_agree_on_random_schemas(seed):
+    """The two oracle walkers (pure Python / C) are independent restatements: they must agree on random
+    schemas x random records too (tests/random_cases.py), incl. multi-block and negative-count containers."""
+    import random_cases
+    js, recs = random_cases.random_case(seed, 60)
+    a = py_walker.decode(recs, js)
+    b = c_walker.decode(recs, js)
+    assert_batches_identical(a, b)
+    a.validate(full=True)
+
+
 def test_schema_translation_details():
     s = S.parse_schema(SCHEMAS["full"])
     sch = S.to_arrow_schema(s)
