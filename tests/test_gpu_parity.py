@@ -124,6 +124,32 @@ def test_random_schemas_and_records(seed, kernel):
     _check(recs, js, 1 + seed % 4)
 
 
+def test_concurrent_calls_from_python_threads(kernel):
+    """The reference releases the GIL around the native call and is safe for concurrent callers
+    (src/lib.rs:64-68,82-86); so is the engine: shared schema cache, pooled memory, one device."""
+    import threading
+    jobs = [("full", 3000, 4), ("cfg3", 5000, 3), ("flat4", 7000, 2), ("array_and_map", 2000, 5)]
+    inputs = {name: synth.records(name, n, seed=11) for name, n, _ in jobs}
+    expect = {name: c_walker.decode_threaded(inputs[name], SCHEMAS[name], k) for name, _, k in jobs}
+    errors = []
+
+    def work(name, k):
+        try:
+            for _ in range(6):
+                got = P.deserialize_array_threaded(inputs[name], SCHEMAS[name], k)
+                for g, e in zip(got, expect[name]):
+                    assert_batches_identical(g, e)
+        except Exception as ex:  # noqa: BLE001 - reported below
+            errors.append((name, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(name, k)) for name, _, k in jobs for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_chunk_semantics():
     recs = synth.records("full", 103)
     for k, want in ((1, [103]), (8, [12] * 7 + [19]), (0, [103]), (103, [1] * 103), (500, [1] * 103), (2, [51, 52])):
