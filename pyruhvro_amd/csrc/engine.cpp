@@ -253,10 +253,10 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile) {
   return s->spec[device];
 }
 
-int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t lds, hipStream_t stream) {
+int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream) {
   rh::KParams copy = P;
   void* args[] = {&copy};
-  return (int)hipModuleLaunchKernel(f, grid, 1, 1, rh::kBlock, 1, 1, lds, stream, args, nullptr);
+  return (int)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, stream, args, nullptr);
 }
 
 std::string format_error(const rh::ErrInfo& e) {
@@ -515,11 +515,6 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   r.sz = n / k;
   r.rows_last = n - (uint64_t)(k - 1) * r.sz;
   const int K = cs.K, nnodes = (int)cs.nodes.size(), nbuf = (int)cs.bufs.size();
-  const uint64_t bpc64 = std::max<uint64_t>((r.sz + rh::kBlock - 1) / rh::kBlock, 1);
-  const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + rh::kBlock - 1) / rh::kBlock;
-  if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
-  const uint32_t nblocks = (uint32_t)nblocks64;
-
   const DeviceProgram& dp = device_program(s, device);
 
   // kernel form: schema-specialised (compiled once per schema, cached) or the generic interpreter
@@ -533,6 +528,12 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (k0.ok) sk = &k0;
     else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
   }
+  const uint64_t tile = sk ? (uint64_t)rh::spec_tile_records() : (uint64_t)rh::kBlock;   // records per workgroup
+  const uint64_t bpc64 = std::max<uint64_t>((r.sz + tile - 1) / tile, 1);
+  const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + tile - 1) / tile;
+  if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
+  const uint32_t nblocks = (uint32_t)nblocks64;
+
 
   // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
   const uint64_t o_null = 16;
@@ -543,7 +544,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
   const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
   const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
-  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 2ull * K * nblocks * rh::kBlock : 0), kAlign);
+  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 2ull * K * nblocks * tile : 0), kAlign);
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
   HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
@@ -566,10 +567,10 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)
-  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
+  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
   const uint64_t avg = n ? data_len / n + 1 : 16;
-  uint64_t win = align_up(avg * rh::kBlock * 115 / 100 + 2048, 16);
-  win = std::max<uint64_t>(win, 8192);
+  uint64_t win = align_up(avg * tile * 115 / 100 + 2048 * tile / rh::kBlock, 16);
+  win = std::max<uint64_t>(win, 8192 * tile / rh::kBlock);
   const uint64_t lds_cap = 160 * 1024 - 512;
   if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
   win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
@@ -592,7 +593,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (!fb) return;
     const uint64_t rec = ~fb;
     uint64_t c = r.sz ? std::min<uint64_t>(rec / r.sz, k - 1) : 0;
-    uint64_t b = c * bpc64 + (rec - c * r.sz) / rh::kBlock;
+    uint64_t b = c * bpc64 + (rec - c * r.sz) / tile;
     rh::ErrInfo ei;
     HIPCHK(hipMemcpy(&ei, P.errinfo + b, sizeof ei, hipMemcpyDeviceToHost));
     throw DecodeError(format_error(ei));
@@ -601,7 +602,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   ev.rec(0, stream);
   std::vector<uint64_t> totals((size_t)K * k, 0);
   if (n > 0 && K > 0) {
-    if (sk ? launch_module(sk->size_fn, P, nblocks, lds_bytes, stream) : rh_launch_size(&P, lds_bytes, stream))
+    if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream) : rh_launch_size(&P, lds_bytes, stream))
       throw HipError("k_size launch failed");
     ev.rec(1, stream);
     if (rh_launch_scan(&P, stream)) throw HipError("k_scan launch failed");
@@ -674,7 +675,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   uint32_t emit_lds = 0;
   if (n > 0) {
     emit_lds = lds_bytes;
-    if (sk ? launch_module(sk->emit_fn, P, nblocks, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
+    if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
       throw HipError("k_emit launch failed");
   }
   ev.rec(4, stream);

@@ -10,7 +10,7 @@ namespace rh {
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-// One workgroup = 256 consecutive records of ONE output chunk (chunk boundaries of
+// One workgroup = one tile = TILE (256 by default) consecutive records of ONE output chunk (chunk boundaries of
 // ruhvro/src/deserialize.rs:57-68: k-1 chunks of sz rows, the last one takes the remainder).
 struct Geo {
   uint32_t chunk;
@@ -19,6 +19,7 @@ struct Geo {
   uint32_t nrec;      // live rows in this workgroup (1..256)
 };
 
+template <int TILE = kBlock>
 __device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
   Geo g;
   uint32_t chunk = b / P.bpc;
@@ -26,10 +27,10 @@ __device__ __forceinline__ Geo geometry(const KParams& P, uint32_t b) {
   const uint32_t lb = b - chunk * P.bpc;
   const uint64_t rows_c = chunk == P.k - 1 ? P.rows_last : P.sz;
   g.chunk = chunk;
-  g.lrow0 = lb * kBlock;
+  g.lrow0 = lb * TILE;
   g.rec0 = (uint64_t)chunk * P.sz + g.lrow0;
   const uint64_t left = rows_c - g.lrow0;
-  g.nrec = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
+  g.nrec = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
   return g;
 }
 
@@ -43,23 +44,24 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) 
 }
 
 // Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction).
-// The loads of a batch of 8 vectors per thread are ALL issued before the first LDS store, so a
-// workgroup pays one HBM round trip per 32 KiB of window instead of one per 4 KiB.
+// The loads of a batch of 8..12 vectors per thread are ALL issued before the first LDS store, so a
+// workgroup pays one HBM round trip per window instead of one per vector.
+template <int TILE = kBlock>
 __device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uint64_t wb16, uint64_t we, uint32_t tid) {
   const uint32_t nvec = (uint32_t)((we - wb16 + 15) >> 4);
   const uint8_t* g = P.data + wb16;
   const uint32_t nfull = (uint32_t)(wb16 + ((uint64_t)nvec << 4) <= P.data_len ? nvec : (P.data_len - wb16) >> 4);   // whole vectors inside the payload
-  constexpr int kBatch = 8;
-  for (uint32_t base = 0; base < nfull; base += kBatch * kBlock) {
+  constexpr int kBatch = TILE >= 256 ? 8 : TILE >= 128 ? 10 : 12;   // window bytes in flight per round: 32 / 20 / 12 KiB
+  for (uint32_t base = 0; base < nfull; base += kBatch * TILE) {
     v4u r[kBatch];
 #pragma unroll
     for (int j = 0; j < kBatch; j++) {
-      const uint32_t i = base + j * kBlock + tid;
+      const uint32_t i = base + j * TILE + tid;
       if (i < nfull) r[j] = *reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(g + ((size_t)i << 4)));
     }
 #pragma unroll
     for (int j = 0; j < kBatch; j++) {
-      const uint32_t i = base + j * kBlock + tid;
+      const uint32_t i = base + j * TILE + tid;
       if (i < nfull) reinterpret_cast<v4u*>(win)[i] = r[j];
     }
   }

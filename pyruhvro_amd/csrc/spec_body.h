@@ -78,10 +78,18 @@ struct SCtx {
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
 
-// LDS in front of the window: wtot[K][4] | nullcnt[NNODES] | misc[4]   (host mirror: rh_spec_lds_fixed_bytes)
-__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes) {
-  return (uint32_t)(K > 0 ? K : 1) * 4 + (uint32_t)((nnodes + 3) & ~3) + 4;
+// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4]   (host mirror: spec_lds_fixed_words_host)
+__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw) {
+  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4;
 }
+
+// Tile geometry of a specialised kernel: S::TILE records = S::TILE threads = NW wavefronts per workgroup.
+template <class S>
+struct TileOf {
+  static constexpr int T = S::TILE;
+  static constexpr int NW = S::TILE / 64;
+  static_assert(S::TILE == 64 || S::TILE == 128 || S::TILE == 256 || S::TILE == 512 || S::TILE == 1024, "tile must be 1..16 wavefronts");
+};
 
 template <class S>
 struct SpecSmem {
@@ -91,7 +99,7 @@ struct SpecSmem {
   uint8_t* win;
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
-    wtot = p; p += (S::K > 0 ? S::K : 1) * 4;
+    wtot = p; p += ((S::K > 0 ? S::K : 1) * (S::TILE / 64) + 3) & ~3;
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
     misc = p; p += 4;
     win = reinterpret_cast<uint8_t*>(p);
@@ -127,14 +135,15 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW;
   const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
-  const Geo g = geometry(P, tile);
+  const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
-  if (fits) stage_window(P, s.win, wb16, we, tid);
+  if (fits) stage_window<T>(P, s.win, wb16, we, tid);
   if (tid == 0) { s.misc[0] = 0xFFFFFFFFu; s.misc[2] = 0; }
   __syncthreads();
   RH_MARK(16);
@@ -154,16 +163,18 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     constexpr int k = decltype(ik)::value;
     const uint32_t cv = c.cnt[k];
     sat |= cv > 0xFFFFu;
-    st_global<uint16_t, false>(P.lanecnt + (size_t)k * ((size_t)P.nblocks * kBlock), tile * kBlock + tid, (uint16_t)(cv > 0xFFFFu ? 0xFFFFu : cv));
+    st_global<uint16_t, false>(P.lanecnt + (size_t)k * ((size_t)P.nblocks * T), tile * T + tid, (uint16_t)(cv > 0xFFFFu ? 0xFFFFu : cv));
     const uint32_t v = wave_sum(cv);
-    if (lane == 0) s.wtot[k * 4 + wave] = v;
+    if (lane == 0) s.wtot[k * NW + wave] = v;
   });
   if (S::K > 0 && __any(sat) && lane == 0) atomicOr(&s.misc[2], 1u);
   report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
   if (S::K > 0 && tid == 0) P.tileflag[tile] = s.misc[2];
-  if ((int)tid < S::K)
-    P.blocksum[(size_t)tid * P.nblocks + tile] =
-        s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
+  for (int k = tid; k < S::K; k += T) {
+    uint32_t tsum = 0;
+    for (int w = 0; w < NW; w++) tsum += s.wtot[k * NW + w];
+    P.blocksum[(size_t)k * P.nblocks + tile] = tsum;
+  }
   RH_MARK(19);
   RH_MARK_FLUSH;
 }
@@ -177,8 +188,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW;
   const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
-  const Geo g = geometry(P, tile);
+  const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
@@ -200,14 +212,14 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     rewalk = P.tileflag[tile];
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
-      c.cnt[k] = (P.lanecnt + (size_t)k * ((size_t)P.nblocks * kBlock))[tile * kBlock + tid];
+      c.cnt[k] = (P.lanecnt + (size_t)k * ((size_t)P.nblocks * T))[tile * T + tid];
     });
   }
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);
-  if (fits) stage_window(P, s.win, wb16, we, tid);
-  for (int i = tid; i < S::NNODES; i += kBlock) s.nullcnt[i] = 0;
+  if (fits) stage_window<T>(P, s.win, wb16, we, tid);
+  for (int i = tid; i < S::NNODES; i += T) s.nullcnt[i] = 0;
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
   RH_MARK(1);
@@ -223,7 +235,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       constexpr int k = decltype(ik)::value;
       const uint32_t v = c.cnt[k];
       const uint32_t incl = wave_incl_scan(v, lane);
-      if (lane == 63) s.wtot[k * 4 + wave] = incl;
+      if (lane == 63) s.wtot[k * NW + wave] = incl;
       c.cnt[k] = incl - v;
     });
     RH_MARK(4);
@@ -231,8 +243,11 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     RH_MARK(5);
     static_for<0, S::K>([&](auto ik) {   // workgroup-local exclusive prefix
       constexpr int k = decltype(ik)::value;
-      const uint32_t w0 = s.wtot[k * 4], w1 = s.wtot[k * 4 + 1], w2 = s.wtot[k * 4 + 2];
-      c.cnt[k] += (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+      if constexpr (NW > 1) {
+        uint32_t pre = 0;
+        for (int w = 0; w < NW - 1; w++) pre += (int)wave > w ? s.wtot[k * NW + w] : 0u;
+        c.cnt[k] += pre;
+      }
     });
   }
 
@@ -249,7 +264,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
 
   report_errors(P, s.misc, L, g, tid, tile);   // barrier inside: nullcnt + staging complete
   RH_MARK(8);
-  for (int i = tid; i < S::NNODES; i += kBlock) {
+  for (int i = tid; i < S::NNODES; i += T) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
   }

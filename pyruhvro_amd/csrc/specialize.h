@@ -7,6 +7,8 @@
 
 namespace rh {
 
+// Records (= threads) per workgroup of the specialised kernels: 256 unless RUHVRO_HIP_TILE says 64, 128, 512 or 1024.
+int spec_tile_records();
 // HIP source of the specialised k_size / k_emit pair for this schema.
 std::string generate_kernel_source(const CompiledSchema& cs);
 // Content hash of (source + the device headers it includes): the on-disk cache key.
@@ -19,8 +21,8 @@ std::vector<char> compile_kernel(const std::string& source, std::string& log);
 std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache);
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
-inline uint32_t spec_lds_fixed_words_host(int K, int nnodes) {
-  return (uint32_t)(K > 0 ? K : 1) * 4 + (uint32_t)((nnodes + 3) & ~3) + 4;
+inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw) {
+  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4;
 }
 
 }  // namespace rh
