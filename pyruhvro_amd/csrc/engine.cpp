@@ -275,6 +275,7 @@ std::string format_error(const rh::ErrInfo& e) {
     case rh::E_LIST_RANGE:
       std::snprintf(buf, sizeof buf, "array/map block count %lld of zero-width items exceeds the supported range", (long long)e.detail);
       return buf;
+    case rh::E_INTERNAL: return "internal error: the fast and the careful walk disagree on a record";
     default: return "decode error";
   }
 }
@@ -612,6 +613,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     check_bad(hctrl.ptr());
     std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
   } else {
+    // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
+    if (sk && n > 0) HIPCHK(hipMemsetAsync(ws.ptr() + o_flag, 0x02, 4ull * nblocks, stream));
     ev.rec(1, stream);
     ev.rec(2, stream);
   }

@@ -78,6 +78,7 @@ __device__ __forceinline__ void lane_init_from(Lane& L, const Geo& g, uint64_t o
   L.pres = L.live;
   L.err = 0;
   L.edetail = 0;
+  L.redo = false;
   L.pstk = 0; L.lstk = 0; L.sstk = 0;
   L.cur = L.live ? (uint32_t)(o0 - wb16) : 0;
   L.end = L.live ? (uint32_t)(o1 - wb16) : 0;
@@ -88,6 +89,7 @@ __device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& 
   L.pres = L.live;
   L.err = 0;
   L.edetail = 0;
+  L.redo = false;
   L.pstk = 0; L.lstk = 0; L.sstk = 0;
   L.cur = 0; L.end = 0;
   if (L.live) {

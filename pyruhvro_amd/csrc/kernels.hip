@@ -66,17 +66,17 @@ __device__ __forceinline__ void walk(const KParams& P, const ICtx& c, const Src&
     const Op op = P.prog[pc];
     switch (op.code) {
       case OP_END: return;
-      case OP_FIXED: h_fixed<EMIT>(c, src, L, op); break;
+      case OP_FIXED: h_fixed<EMIT, true>(c, src, L, op); break;
       case OP_STRING:
-      case OP_ENUM: h_string<EMIT>(c, src, L, op); break;
-      case OP_REC_BEGIN: h_rec_begin<EMIT>(c, src, L, op); break;
+      case OP_ENUM: h_string<EMIT, true>(c, src, L, op); break;
+      case OP_REC_BEGIN: h_rec_begin<EMIT, true>(c, src, L, op); break;
       case OP_REC_END: h_rec_end(L); break;
-      case OP_UNION_BEGIN: h_union_begin<EMIT>(c, src, L, op); break;
+      case OP_UNION_BEGIN: h_union_begin<EMIT, true>(c, src, L, op); break;
       case OP_VARIANT: h_variant(L, op); break;
       case OP_UNION_END: h_union_end(L); break;
-      case OP_LIST_BEGIN: h_list_begin<EMIT>(c, src, L, op); break;
+      case OP_LIST_BEGIN: h_list_begin<EMIT, true>(c, src, L, op); break;
       case OP_LIST_NEXT:
-        if (!h_list_next(c, src, L, op)) { pc = op.b; continue; }
+        if (!h_list_next<true>(c, src, L, op)) { pc = op.b; continue; }
         break;
       case OP_LIST_TAIL:
         h_list_tail(c, L, op);

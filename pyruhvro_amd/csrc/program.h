@@ -68,6 +68,7 @@ struct Op {
 enum ErrCode : uint32_t {
   E_OK = 0, E_EOB, E_VARINT, E_EOB_F32, E_EOB_F64, E_BOOL, E_NEGLEN, E_EOB_STR, E_ENUM, E_BRANCH, E_UNION,
   E_LIST_RANGE,   // zero-width items with a block count beyond the i32 offset range (no reference message)
+  E_INTERNAL,     // the fast emit walk met a wire form the size pass had not flagged (cannot happen; never silent)
 };
 
 struct ErrInfo {
@@ -118,7 +119,7 @@ struct KParams {
   uint32_t* nullcount;       // [nnodes][k]
   // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
   uint16_t* lanecnt;         // [K][nblocks*256] per-record counters, saturated at 0xFFFF
-  uint32_t* tileflag;        // [nblocks] 1 = a counter of this tile saturated: k_emit re-runs the size walk
+  uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
 };
 

@@ -106,14 +106,16 @@ struct SpecSmem {
   }
 };
 
-template <class S, bool EMIT>
+// CAREFUL = false: the branch-free fast walk out of the LDS window (walk.h `reject`); tiles whose window does not
+// fit LDS are always walked carefully, straight from global memory.
+template <class S, bool EMIT, bool CAREFUL>
 __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
     LdsSrc src{win};
-    S::template walk<EMIT>(c, src, L);
+    S::template walk<EMIT, CAREFUL>(c, src, L);
   } else {
     GlobalSrc src{P.data + wb16, P.data_len - wb16};
-    S::template walk<EMIT>(c, src, L);
+    S::template walk<EMIT, true>(c, src, L);
   }
 }
 
@@ -154,7 +156,15 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
   RH_MARK(17);
-  spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+  spec_run_walk<S, false, false>(P, c, s.win, L, fits, wb16);
+  bool careful = !fits;
+  if (__any(L.redo)) {   // some record of this wave left the fast wire forms (or is malformed): walk the wave again, carefully
+    careful = true;
+    spec_ctx_init(c, P, s, g, tid);
+    lane_init_from(L, g, o0, o1, wb16, tid);
+    if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
+    spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
+  }
   RH_MARK(18);
 
   // per-record counters -> HBM (2 bytes each, coalesced per counter) so that k_emit can skip its size walk
@@ -167,9 +177,10 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     const uint32_t v = wave_sum(cv);
     if (lane == 0) s.wtot[k * NW + wave] = v;
   });
-  if (S::K > 0 && __any(sat) && lane == 0) atomicOr(&s.misc[2], 1u);
+  const bool anysat = __any(sat);
+  if (lane == 0 && (anysat || careful)) atomicOr(&s.misc[2], (anysat ? 1u : 0u) | (careful ? 2u : 0u));
   report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
-  if (S::K > 0 && tid == 0) P.tileflag[tile] = s.misc[2];
+  if (tid == 0) P.tileflag[tile] = s.misc[2];
   for (int k = tid; k < S::K; k += T) {
     uint32_t tsum = 0;
     for (int w = 0; w < NW; w++) tsum += s.wtot[k * NW + w];
@@ -207,9 +218,10 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
   // this record's counters as k_size left them (requested with the window, so no extra round trip)
-  uint32_t rewalk = 0;
+  const uint32_t tflag = P.tileflag[tile];
+  const uint32_t rewalk = tflag & 1u;
+  const bool careful = (tflag & 2u) != 0;
   if (S::K > 0) {
-    rewalk = P.tileflag[tile];
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
       c.cnt[k] = (P.lanecnt + (size_t)k * ((size_t)P.nblocks * T))[tile * T + tid];
@@ -228,7 +240,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     if (rewalk) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
       static_for<0, S::K>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
       lane_init_from(L, g, o0, o1, wb16, tid);
-      spec_run_walk<S, false>(P, c, s.win, L, fits, wb16);
+      spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
     }
     RH_MARK(3);
     static_for<0, S::K>([&](auto ik) {
@@ -254,7 +266,12 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(6);
   lane_init_from(L, g, o0, o1, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-  spec_run_walk<S, true>(P, c, s.win, L, fits, wb16);
+  if (careful) {
+    spec_run_walk<S, true, true>(P, c, s.win, L, fits, wb16);
+  } else {
+    spec_run_walk<S, true, false>(P, c, s.win, L, fits, wb16);
+    if (L.redo) L.err = E_INTERNAL;   // k_size walks the same bytes and would have flagged the tile
+  }
   RH_MARK(7);
   if (lane == 0)
     static_for<0, S::NNODES>([&](auto in) {

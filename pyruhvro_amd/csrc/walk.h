@@ -167,6 +167,7 @@ struct Lane {
   uint32_t err;        // ErrCode, 0 = ok
   int64_t edetail;
   bool live, pres;     // an errored lane is dead: live = pres = false and its saved bits are cleared
+  bool redo;           // fast walk only: this record left the fast wire forms and must be walked carefully
   uint32_t pstk;       // saved `pres` bits   (nullable record / union / list)
   uint32_t lstk;       // saved `live` bits   (list)
   uint64_t sstk;       // saved union selectors, 8 bits each
@@ -181,6 +182,26 @@ __device__ __forceinline__ void fail(Lane& L, uint32_t code, int64_t detail = 0)
   L.pres = false;
   L.pstk = 0;
   L.lstk = 0;
+}
+
+// Two forms of every walk.  CAREFUL: anomalies (malformed input, and wire forms outside the single-read
+// fast path) are resolved on the spot, behind wave-uniform branches, with the reference's exact error order.
+// FAST (CAREFUL = false): no such branch exists at all -- a lane that meets ANY anomaly just marks `redo`
+// and dies, fully predicated; whoever ran the fast walk re-runs the careful one for that wave / tile.  The
+// size kernel finds out which tiles need it (almost none do) and tells the emit kernel (tileflag bit 1).
+template <bool CAREFUL>
+__device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_t detail = 0) {
+  if (CAREFUL) {
+    if (__any(cond)) {
+      if (cond) fail(L, code, detail);
+    }
+  } else {
+    L.redo = L.redo || cond;
+    L.live = L.live && !cond;
+    L.pres = L.pres && !cond;
+    L.pstk = cond ? 0u : L.pstk;
+    L.lstk = cond ? 0u : L.lstk;
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -260,7 +281,7 @@ __device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nul
 // Head of a field for the lanes with `dec`: an optional single-byte null-union branch and an optional
 // varint (`wide`: may need more than 28 bits).  Returns isval (false for lanes without `dec`); v is the
 // varint when isval && want_varint.  L.cur moves past what was read.
-template <class Src>
+template <bool CAREFUL, class Src>
 __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
                                          bool wide, int64_t& v) {
   if (!nullable && !want_varint) return dec;
@@ -290,11 +311,16 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   }
   const bool slow = dec && (!okb || (isval && !okv));
   uint32_t adv = skip + ((isval && want_varint) ? n : 0u);
-  if (__any(slow)) {
-    if (slow) {
-      isval = read_head_slow(src, L, nullable, null_first, want_varint, v);
-      adv = 0;
+  if (CAREFUL) {
+    if (__any(slow)) {
+      if (slow) {
+        isval = read_head_slow(src, L, nullable, null_first, want_varint, v);
+        adv = 0;
+      }
     }
+  } else {
+    reject<false>(L, slow, 0);
+    isval = isval && !slow;
   }
   L.cur += dec ? adv : 0u;
   return isval;
@@ -335,14 +361,14 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
 // field handlers
 // --------------------------------------------------------------------------
 // int/long/float/double/boolean/date/timestamp leaf, optionally Nullable* (424-432, 434-473)
-template <bool EMIT, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   const bool dec = act && L.pres;
   const bool is_int = op.a == FK_I32 || op.a == FK_I64;
   int64_t v = 0;
-  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
-                               op.a == FK_I64, v);
+  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
+                                        op.a == FK_I64, v);
   uint64_t bits;
   bool valid;
   if (is_int) {
@@ -356,10 +382,8 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     const bool eob = want && avail < need;
     bits = op.a == FK_F32 ? (uint64_t)(uint32_t)x : op.a == FK_F64 ? x : (x & 0xFFu);
     const bool badb = want && !eob && op.a == FK_BOOL && bits > 1;   // read_bool, 893-900
-    if (__any(eob || badb)) {
-      if (eob) fail(L, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
-      else if (badb) fail(L, E_BOOL, (int64_t)bits);
-    }
+    reject<CAREFUL>(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
+    reject<CAREFUL>(L, badb, E_BOOL, (int64_t)bits);
     valid = want && L.live;
     L.cur += valid ? need : 0u;
   }
@@ -383,29 +407,25 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
 }
 
 // string leaf / map key (429, 454-457, 752, read_string 902-922) and enum -> symbol text (570-578)
-template <bool EMIT, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   const bool dec = act && L.pres;
   int64_t v = 0;
-  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
+  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   if (op.code == OP_STRING) {
     const bool neg = want && v < 0;
     const bool eob = want && !neg && (uint64_t)v > (uint64_t)(L.end - L.cur);
-    if (__any(neg || eob)) {
-      if (neg) fail(L, E_NEGLEN);
-      else if (eob) fail(L, E_EOB_STR);
-    }
+    reject<CAREFUL>(L, neg, E_NEGLEN);
+    reject<CAREFUL>(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
     spos = L.cur;
     L.cur += len;
   } else {
     const bool oor = want && (uint64_t)v >= (uint64_t)op.c;
-    if (__any(oor)) {
-      if (oor) fail(L, E_ENUM, v);
-    }
+    reject<CAREFUL>(L, oor, E_ENUM, v);
     if (want && L.live) {
       spos = c.sym_off[op.b + (int32_t)v];
       len = c.sym_off[op.b + (int32_t)v + 1] - spos;
@@ -436,13 +456,13 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
 }
 
 // NullableRecord (482-485 + 595-616): a null record null-fills its children
-template <bool EMIT, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.pres = valid;
@@ -453,18 +473,16 @@ __device__ __forceinline__ void h_rec_end(Lane& L) {
 }
 
 // UnionDecoder::decode / append_null (643-668): selected variant decodes, every other one null-fills
-template <bool EMIT, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   L.sstk = (L.sstk << 8) | 0xFFull;
   const bool dec = act && L.pres;
   int64_t idx = 0;
-  const bool got = read_head(src, L, dec, false, false, true, false, idx) && L.live;
+  const bool got = read_head<CAREFUL>(src, L, dec, false, false, true, false, idx) && L.live;
   const bool oor = got && (idx < 0 || idx >= (int64_t)op.a);
-  if (__any(oor)) {
-    if (oor) fail(L, E_UNION, idx);
-  }
+  reject<CAREFUL>(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
   if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
   if (EMIT && act) st_global<int8_t, Ctx::kWide>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
@@ -479,14 +497,14 @@ __device__ __forceinline__ void h_union_end(Lane& L) {
 }
 
 // ListDecoder / MapDecoder (+ Nullable*), 487-496, 703-770
-template <bool EMIT, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.live = valid;      // only rows that really carry a list enter the block loop
@@ -525,7 +543,7 @@ __device__ __forceinline__ void list_next_slow(const Ctx& c, const Src& src, Lan
 }
 
 // Head of the block loop.  Returns true while any lane of the wave still has an item (wave-uniform).
-template <class Src, class Ctx>
+template <bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   uint32_t& rm = c.remaining(op.c);
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
@@ -544,8 +562,12 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
       rm = cnt < cap ? cnt : cap;
     }
   }
-  if (__any(slow)) {
-    if (slow) list_next_slow(c, src, L, op, rm);
+  if (CAREFUL) {
+    if (__any(slow)) {
+      if (slow) list_next_slow(c, src, L, op, rm);
+    }
+  } else {
+    reject<false>(L, slow, 0);
   }
   if (!__any(L.live)) return false;
   L.pres = L.live;

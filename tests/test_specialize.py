@@ -12,12 +12,12 @@ def test_generated_source_follows_the_schema_program():
     src = cabi.kernel_source(SCHEMAS["full"])
     assert '#include "spec_body.h"' in src and "rh_spec_size" in src and "rh_spec_emit" in src
     # full schema (scripts/generate_avro.py): 2 list loops (emails, phone_numbers), one 4-variant union, 2 nullable records
-    assert src.count("h_list_begin<EMIT>") == 2 and src.count("for (;;)") == 2
-    assert src.count("h_union_begin<EMIT>") == 1 and src.count("h_variant(") == 4
-    assert src.count("h_rec_begin<EMIT>") == 2 and src.count("h_rec_end(L)") == 2
+    assert src.count("h_list_begin<EMIT, CAREFUL>") == 2 and src.count("for (;;)") == 2
+    assert src.count("h_union_begin<EMIT, CAREFUL>") == 1 and src.count("h_variant(") == 4
+    assert src.count("h_rec_begin<EMIT, CAREFUL>") == 2 and src.count("h_rec_end(L)") == 2
     assert "static constexpr int K = 12, NDOM = 3" in src
     flat = cabi.kernel_source(SCHEMAS["flat4"])
-    assert "static constexpr int K = 0, NDOM = 1" in flat and flat.count("h_fixed<EMIT>") == 4
+    assert "static constexpr int K = 0, NDOM = 1" in flat and flat.count("h_fixed<EMIT, CAREFUL>") == 4
 
 
 def test_prebuild_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
