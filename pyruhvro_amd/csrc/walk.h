@@ -101,12 +101,8 @@ struct GlobalSrc {
 // WIDE = false: the byte offset idx * sizeof(T) is formed in 32 bits, so the store takes the
 // uniform-base + 32-bit-lane-offset addressing form (no 64-bit address arithmetic per lane).  The host
 // only launches kernels built that way when every buffer of a chunk is smaller than 4 GiB.
-#ifndef RH_EXP
-#define RH_EXP 0
-#endif
 template <class T, bool WIDE>
 __device__ __forceinline__ void st_global(void* base, uint32_t idx, T v) {
-  if (RH_EXP == 2) return;
   if (WIDE) {
     reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base))[(uint64_t)idx] = v;
   } else {
@@ -126,7 +122,6 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
 // instruction count is what matters.)  Both window reads of a round are issued before the first store.
 template <class Src>
 __device__ __forceinline__ void copy_bytes(RH_GLOBAL uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
-  if (RH_EXP == 1 || RH_EXP == 2) return;
   if (len >= 8) {
     uint32_t j = 0;
     for (; j + 16 <= len; j += 16) {
