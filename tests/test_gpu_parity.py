@@ -175,6 +175,28 @@ def test_input_forms(kernel):
         assert_batches_identical(x, y)
 
 
+def test_arrow_binary_array_input():
+    """Records already in an Arrow BinaryArray / LargeBinaryArray (zero-copy ingest), incl. sliced arrays."""
+    recs = synth.records("full", 2500)
+    exp = c_walker.decode_threaded(recs, SCHEMAS["full"], 4)
+    for typ in (pa.binary(), pa.large_binary()):
+        arr = pa.array(recs, type=typ)
+        got = P.deserialize_binary_array(arr, SCHEMAS["full"], 4)
+        assert len(got) == 4
+        for g, e in zip(got, exp):
+            assert_batches_identical(g, e)
+    sl = pa.array([b"junk"] * 7 + recs + [b"x"], type=pa.binary()).slice(7, len(recs))
+    for g, e in zip(P.deserialize_binary_array(sl, SCHEMAS["full"], 4), exp):
+        assert_batches_identical(g, e)
+    ch = pa.chunked_array([pa.array(recs[:1000], type=pa.binary()), pa.array(recs[1000:], type=pa.binary())])
+    for g, e in zip(P.deserialize_binary_array(ch, SCHEMAS["full"], 4), exp):
+        assert_batches_identical(g, e)
+    empty = P.deserialize_binary_array(pa.array([], type=pa.binary()), SCHEMAS["full"], 3)
+    assert [b.num_rows for b in empty] == [0]
+    with pytest.raises(ValueError):
+        P.deserialize_binary_array(pa.array([recs[0], None], type=pa.binary()), SCHEMAS["full"], 1)
+
+
 def test_records_larger_than_the_lds_window():
     # 256 x 70 KB strings overflow any LDS window -> the global-memory read path of the same kernels
     s = SCHEMAS["flat_primitives"]

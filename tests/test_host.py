@@ -153,6 +153,16 @@ def test_argument_errors_without_touching_the_gpu():
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device failure mode")
+def test_binary_array_argument_errors():
+    import pyarrow as pa
+    with pytest.raises(TypeError):
+        P.deserialize_binary_array([b"x"], SCHEMAS["flat4"], 1)
+    with pytest.raises(ValueError):
+        P.deserialize_binary_array(pa.array([b"x", None], type=pa.binary()), SCHEMAS["flat4"], 1)
+    with pytest.raises(ValueError):
+        P.deserialize_binary_array(pa.array([b"x"], type=pa.binary()), '{"type":"string"}', 1)
+
+
 def test_no_device_fails_loudly_no_cpu_fallback():
     with pytest.raises(RuntimeError) as ei:
         P.deserialize_array([b"\x00\x00" + b"\x00" * 8 + b"\x00"], SCHEMAS["flat4"])
