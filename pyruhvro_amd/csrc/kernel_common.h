@@ -43,31 +43,51 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) 
   return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
 }
 
-// Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction).
-// The loads of a batch of 8..12 vectors per thread are ALL issued before the first LDS store, so a
-// workgroup pays one HBM round trip per window instead of one per vector.
+// One straight-line round of the window load: up to KB rows of TILE 16-byte vectors.  Every load is issued
+// before the first LDS store.  Whole rows carry no per-lane predicate (the row count is wave-uniform); only the
+// last, partial row is predicated.  Deliberately NOT a loop: with a loop the register array is loop-carried and
+// the compiler protects each element with an s_waitcnt vmcnt(0) BEFORE re-loading it, which serialises every
+// load behind the previous one's HBM round trip (seen in the ISA; it made this phase 13.5k cycles per wave).
+template <int TILE, int KB>
+__device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t left, uint32_t tid) {
+  const uint32_t rows = left / TILE;            // wave-uniform
+  const uint32_t rem = left - rows * TILE;
+  v4u r[KB];
+#pragma unroll
+  for (int j = 0; j < KB; j++) {
+    if ((uint32_t)j < rows) r[j] = gp[j * TILE];
+    else if ((uint32_t)j == rows && tid < rem) r[j] = gp[j * TILE];
+  }
+#pragma unroll
+  for (int j = 0; j < KB; j++) {
+    if ((uint32_t)j < rows) lp[j * TILE] = r[j];
+    else if ((uint32_t)j == rows && tid < rem) lp[j * TILE] = r[j];
+  }
+}
+
+// Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction): one HBM round trip
+// for windows up to 12 rows (48 KiB at 256 threads), two for the largest windows the host ever configures (96 KiB).
 template <int TILE = kBlock>
 __device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uint64_t wb16, uint64_t we, uint32_t tid) {
   const uint32_t nvec = (uint32_t)((we - wb16 + 15) >> 4);
-  const uint8_t* g = P.data + wb16;
-  const uint32_t nfull = (uint32_t)(wb16 + ((uint64_t)nvec << 4) <= P.data_len ? nvec : (P.data_len - wb16) >> 4);   // whole vectors inside the payload
-  constexpr int kBatch = TILE >= 256 ? 8 : TILE >= 128 ? 10 : 12;   // window bytes in flight per round: 32 / 20 / 12 KiB
-  for (uint32_t base = 0; base < nfull; base += kBatch * TILE) {
-    v4u r[kBatch];
-#pragma unroll
-    for (int j = 0; j < kBatch; j++) {
-      const uint32_t i = base + j * TILE + tid;
-      if (i < nfull) r[j] = *reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(g + ((size_t)i << 4)));
-    }
-#pragma unroll
-    for (int j = 0; j < kBatch; j++) {
-      const uint32_t i = base + j * TILE + tid;
-      if (i < nfull) reinterpret_cast<v4u*>(win)[i] = r[j];
+  // vectors that lie completely inside the payload (only the very last tile of a call can have a ragged one)
+  const uint32_t nfull = (uint32_t)(wb16 + ((uint64_t)nvec << 4) <= P.data_len ? nvec : (P.data_len - wb16) >> 4);
+  constexpr int KB = 12;
+  const RH_GLOBAL v4u* gp = reinterpret_cast<const RH_GLOBAL v4u*>(reinterpret_cast<uintptr_t>(P.data + wb16)) + tid;
+  v4u* lp = reinterpret_cast<v4u*>(win) + tid;
+  const uint32_t first = nfull < (uint32_t)(KB * TILE) ? nfull : (uint32_t)(KB * TILE);
+  stage_rows<TILE, KB>(gp, lp, first, tid);
+  if (nfull > (uint32_t)(KB * TILE)) {
+    uint32_t done = KB * TILE;
+    while (done < nfull) {                        // windows beyond 48 KiB (at 256 threads): further rounds
+      const uint32_t left = nfull - done < (uint32_t)(KB * TILE) ? nfull - done : (uint32_t)(KB * TILE);
+      stage_rows<TILE, KB>(gp + done, lp + done, left, tid);
+      done += left;
     }
   }
   if (nfull < nvec && tid < 16) {   // ragged tail of the payload: bytes, zero-filled past the end
     const uint64_t pos = wb16 + ((uint64_t)nfull << 4);
-    win[(nfull << 4) + tid] = pos + tid < P.data_len ? g[((size_t)nfull << 4) + tid] : 0;
+    win[(nfull << 4) + tid] = pos + tid < P.data_len ? P.data[pos + tid] : 0;
   }
 }
 
