@@ -28,6 +28,8 @@ namespace rh {
 typedef uint64_t __attribute__((aligned(1))) u64u;
 typedef uint32_t __attribute__((aligned(1))) u32u;
 typedef uint16_t __attribute__((aligned(1))) u16u;
+typedef uint32_t v4w __attribute__((ext_vector_type(4)));
+typedef v4w __attribute__((aligned(1))) v4wu;
 
 // --------------------------------------------------------------------------
 // wave primitives (wave = 64 lanes)
@@ -71,6 +73,18 @@ struct LdsSrc {
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     return ((uint64_t)hi << 32) | lo;
   }
+  // 16 bytes at any byte position: five aligned dwords, four v_alignbyte
+  __device__ __forceinline__ v4w ld16(uint32_t p) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+    const uint32_t sh = p & 3u;
+    v4w r;
+    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    r.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    return r;
+  }
   // >= 5 valid bytes (a 1-byte union branch + a varint of <= 4 bytes) from ONE ds_read2_b32
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
@@ -93,6 +107,12 @@ struct GlobalSrc {
     return x;
   }
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
+  __device__ __forceinline__ v4w ld16(uint32_t p) const {
+    const uint64_t lo = ld8(p), hi = ld8(p + 8);
+    v4w r;
+    r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
+    return r;
+  }
 };
 
 // Arrow buffers live in HBM: typed global-address-space accessors keep the compiler from emitting
@@ -115,26 +135,31 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// copy `len` bytes window[sp..] -> d (HBM), any alignment on both sides, with at most TWO store
-// instructions per 16 bytes: the tail of a string is written as the LAST 8 (4, 2) bytes ending at its end,
-// overlapping what the first store already wrote, instead of 4+2+1-byte pieces.  (Unaligned per-lane stores
-// cost ~44 TA cycles per wave instruction on MI355X whatever their width -- tools/gmemalign.hip -- so the
-// instruction count is what matters.)  Both window reads of a round are issued before the first store.
+// copy `len` bytes window[sp..] -> d (HBM), any alignment on both sides, with as few store instructions as
+// possible: 16-byte stores for strings of 16 bytes and more, and the tail of a string written as the LAST
+// 16 (8, 4, 2) bytes ending at its end, overlapping what the first store already wrote, instead of 8+4+2+1-byte
+// pieces -- two stores for any length up to 32.  (Unaligned per-lane stores cost ~44 TA cycles per wave
+// instruction on MI355X whatever their width -- tools/gmemalign.hip -- so the instruction count is what
+// matters.)  All window reads of a round are issued before the first store.  Reads never leave the string.
 template <class Src>
 __device__ __forceinline__ void copy_bytes(RH_GLOBAL uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
-  if (len >= 8) {
+  if (len >= 16) {
     uint32_t j = 0;
-    for (; j + 16 <= len; j += 16) {
-      const uint64_t x0 = s.ld8(sp + j), x1 = s.ld8(sp + j + 8);
-      *reinterpret_cast<RH_GLOBAL u64u*>(d + j) = x0;
-      *reinterpret_cast<RH_GLOBAL u64u*>(d + j + 8) = x1;
+    for (; j + 32 <= len; j += 32) {
+      const v4w x0 = s.ld16(sp + j), x1 = s.ld16(sp + j + 16);
+      *reinterpret_cast<RH_GLOBAL v4wu*>(d + j) = x0;
+      *reinterpret_cast<RH_GLOBAL v4wu*>(d + j + 16) = x1;
     }
-    if (j < len) {   // 1..15 bytes left, and at least 8 bytes precede the end: [j, j+8) if it fits, then the last 8
-      const uint32_t a = j + 8 <= len ? j : len - 8;
-      const uint64_t x0 = s.ld8(sp + a), x1 = s.ld8(sp + len - 8);
-      *reinterpret_cast<RH_GLOBAL u64u*>(d + a) = x0;
-      if (j + 8 < len) *reinterpret_cast<RH_GLOBAL u64u*>(d + len - 8) = x1;
+    if (j < len) {   // 1..31 bytes left: [j, j+16) if it fits, then the last 16
+      const uint32_t a = j + 16 <= len ? j : len - 16;
+      const v4w x0 = s.ld16(sp + a), x1 = s.ld16(sp + len - 16);
+      *reinterpret_cast<RH_GLOBAL v4wu*>(d + a) = x0;
+      if (j + 16 < len) *reinterpret_cast<RH_GLOBAL v4wu*>(d + len - 16) = x1;
     }
+  } else if (len >= 8) {
+    const uint64_t x0 = s.ld8(sp), x1 = s.ld8(sp + len - 8);
+    *reinterpret_cast<RH_GLOBAL u64u*>(d) = x0;
+    if (len > 8) *reinterpret_cast<RH_GLOBAL u64u*>(d + len - 8) = x1;
   } else {
     const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
     if (len >= 4) {
