@@ -150,6 +150,47 @@ def test_concurrent_calls_from_python_threads(kernel):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("name", ["full", "array_and_map", "cfg3", "nullable_primitives"])
+def test_corrupted_records_same_outcome_as_oracle(name, kernel):
+    """Random damage (bit flips, truncation, junk insertion) to valid records: the HIP path must end exactly like
+    the oracle -- the same ValueError text (lowest failing record wins) or the same buffers.  Exercises the
+    fast -> careful re-walk of both kernels on every kind of anomaly."""
+    import random
+    base = synth.records(name, 1500, seed=9)
+    r = random.Random(1234 + len(name))
+    outcomes = {"error": 0, "ok": 0}
+    for trial in range(60):
+        recs = list(base)
+        for _ in range(r.choice([1, 1, 2, 5])):
+            i = r.randrange(len(recs))
+            b = bytearray(recs[i])
+            how = r.randrange(4)
+            if how == 0 and b:
+                b[r.randrange(len(b))] ^= 1 << r.randrange(8)
+            elif how == 1 and b:
+                del b[r.randrange(len(b)):]
+            elif how == 2:
+                pos = r.randrange(len(b) + 1)
+                b[pos:pos] = bytes(r.randrange(256) for _ in range(r.randint(1, 4)))
+            elif b:
+                b[r.randrange(len(b))] = r.choice([0x80, 0xFF, 0x7F, 0x01, 0x00])
+            recs[i] = bytes(b)
+        k = 1 + trial % 5
+        try:
+            exp = c_walker.decode_threaded(recs, SCHEMAS[name], k)
+        except ValueError as e:
+            outcomes["error"] += 1
+            with pytest.raises(ValueError) as ei:
+                P.deserialize_array_threaded(recs, SCHEMAS[name], k)
+            assert str(ei.value) == str(e), (trial, name)
+            continue
+        outcomes["ok"] += 1
+        got = P.deserialize_array_threaded(recs, SCHEMAS[name], k)
+        for g, e in zip(got, exp):
+            assert_batches_identical(g, e)
+    assert outcomes["error"] > 5 and outcomes["ok"] > 0, outcomes
+
+
 def test_chunk_semantics():
     recs = synth.records("full", 103)
     for k, want in ((1, [103]), (8, [12] * 7 + [19]), (0, [103]), (103, [1] * 103), (500, [1] * 103), (2, [51, 52])):
