@@ -141,35 +141,43 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
 // pieces -- two stores for any length up to 32.  (Unaligned per-lane stores cost ~44 TA cycles per wave
 // instruction on MI355X whatever their width -- tools/gmemalign.hip -- so the instruction count is what
 // matters.)  All window reads of a round are issued before the first store.  Reads never leave the string.
-template <class Src>
-__device__ __forceinline__ void copy_bytes(RH_GLOBAL uint8_t* d, const Src& s, uint32_t sp, uint32_t len) {
+// A store of T at byte offset `off` from a uniform buffer base.  WIDE = false: the offset stays 32-bit, so the
+// instruction takes the scalar-base + 32-bit-lane-offset form (no per-lane 64-bit address arithmetic).
+template <class T, bool WIDE>
+__device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
+  if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off) = v;
+  else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
+}
+
+template <bool WIDE, class Src>
+__device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
   if (len >= 16) {
     uint32_t j = 0;
     for (; j + 32 <= len; j += 32) {
       const v4w x0 = s.ld16(sp + j), x1 = s.ld16(sp + j + 16);
-      *reinterpret_cast<RH_GLOBAL v4wu*>(d + j) = x0;
-      *reinterpret_cast<RH_GLOBAL v4wu*>(d + j + 16) = x1;
+      st_at<v4wu, WIDE>(base, d + j, x0);
+      st_at<v4wu, WIDE>(base, d + j + 16, x1);
     }
     if (j < len) {   // 1..31 bytes left: [j, j+16) if it fits, then the last 16
       const uint32_t a = j + 16 <= len ? j : len - 16;
       const v4w x0 = s.ld16(sp + a), x1 = s.ld16(sp + len - 16);
-      *reinterpret_cast<RH_GLOBAL v4wu*>(d + a) = x0;
-      if (j + 16 < len) *reinterpret_cast<RH_GLOBAL v4wu*>(d + len - 16) = x1;
+      st_at<v4wu, WIDE>(base, d + a, x0);
+      if (j + 16 < len) st_at<v4wu, WIDE>(base, d + len - 16, x1);
     }
   } else if (len >= 8) {
     const uint64_t x0 = s.ld8(sp), x1 = s.ld8(sp + len - 8);
-    *reinterpret_cast<RH_GLOBAL u64u*>(d) = x0;
-    if (len > 8) *reinterpret_cast<RH_GLOBAL u64u*>(d + len - 8) = x1;
+    st_at<u64u, WIDE>(base, d, x0);
+    if (len > 8) st_at<u64u, WIDE>(base, d + len - 8, x1);
   } else {
     const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
     if (len >= 4) {
-      *reinterpret_cast<RH_GLOBAL u32u*>(d) = (uint32_t)x;
-      if (len > 4) *reinterpret_cast<RH_GLOBAL u32u*>(d + len - 4) = (uint32_t)(x >> (8 * (len - 4)));
+      st_at<u32u, WIDE>(base, d, (uint32_t)x);
+      if (len > 4) st_at<u32u, WIDE>(base, d + len - 4, (uint32_t)(x >> (8 * (len - 4))));
     } else if (len >= 2) {
-      *reinterpret_cast<RH_GLOBAL u16u*>(d) = (uint16_t)x;
-      if (len > 2) d[2] = (uint8_t)(x >> 16);
+      st_at<u16u, WIDE>(base, d, (uint16_t)x);
+      if (len > 2) st_at<uint8_t, WIDE>(base, d + 2, (uint8_t)(x >> 16));
     } else {
-      d[0] = (uint8_t)x;
+      st_at<uint8_t, WIDE>(base, d, (uint8_t)x);
     }
   }
 }
@@ -436,15 +444,16 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   if (op.code == OP_STRING) {
-    const bool neg = want && v < 0;
-    const bool eob = want && !neg && (uint64_t)v > (uint64_t)(L.end - L.cur);
+    // the fast walk only ever sees lengths from the 28-bit single-read decode: 32-bit compares are enough there
+    const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
+    const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur);
     reject<CAREFUL>(L, neg, E_NEGLEN);
     reject<CAREFUL>(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
     spos = L.cur;
     L.cur += len;
   } else {
-    const bool oor = want && (uint64_t)v >= (uint64_t)op.c;
+    const bool oor = want && (CAREFUL ? (uint64_t)v >= (uint64_t)op.c : (uint32_t)v >= (uint32_t)op.c);
     reject<CAREFUL>(L, oor, E_ENUM, v);
     if (want && L.live) {
       spos = c.sym_off[op.b + (int32_t)v];
@@ -465,9 +474,12 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
         // own neighbouring rows, so one wave store covers one contiguous span of the column.  (Staging the
         // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
         // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
-        RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
-        if (op.code == OP_STRING) copy_bytes(d, src, spos, len);
-        else copy_plain(d, c.sym_data + spos, len);
+        if (op.code == OP_STRING) {
+          copy_bytes<Ctx::kWide>(c.buf(op.buf2), (uint64_t)gb + o, src, spos, len);
+        } else {
+          RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
+          copy_plain(d, c.sym_data + spos, len);
+        }
       }
     }
   }
@@ -501,7 +513,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   const bool dec = act && L.pres;
   int64_t idx = 0;
   const bool got = read_head<CAREFUL>(src, L, dec, false, false, true, false, idx) && L.live;
-  const bool oor = got && (idx < 0 || idx >= (int64_t)op.a);
+  const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   reject<CAREFUL>(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
   if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
