@@ -217,7 +217,7 @@ def main(argv=None):
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "bytes_per_record": alg_bytes / n, "avg_launch_ms": emit_ms},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n), num_chunks)
     print(json.dumps(out))
 
