@@ -127,6 +127,17 @@ void rh_device_result_free(rh_device_result* r);
 char* rh_schema_kernel_source(const rh_schema* s);
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err);
 
+/* Arrow -> Avro, the other direction.  Replaces ruhvro::serialize::serialize_record_batch
+ * (ruhvro/src/serialize.rs:38-67) + fast_encode::serialize_chunk (ruhvro/src/fast_encode.rs:27-53): `batch` is
+ * the record batch as a struct array (Arrow C Data Interface, any offsets / slices), columns are matched to the
+ * schema's fields BY NAME (fast_encode.rs:151-185).  out_chunks[0..*out_k) are BinaryArrays ("z": i32 offsets +
+ * data, one datum per row) in host memory, chunked like serialize.rs:19-30; the caller provides room for
+ * rh_clamp_chunks(batch->length, num_chunks) entries and releases each through ArrowArray.release.  Data-dependent
+ * failures return RH_ERR_DECODE with the reference's message text (fast_encode.rs:173-177, 541, 576). */
+int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema,
+              uint64_t num_chunks, const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k,
+              rh_stats* stats, char** err);
+
 void rh_free_string(char* s);
 int rh_abi_version(void);
 /* Number of visible HIP devices (0 when no GPU / driver); never throws. */

@@ -167,14 +167,53 @@ def deserialize_binary_array(array, schema, num_chunks):
     return cabi.decode_packed(data, offsets, schema, num_chunks, kernel=_kernel_mode)
 
 
+def _encode(data, schema: str, num_chunks: int, want_stats: bool = False, device: int = -1, stream: int = 0):
+    import ctypes
+    comp = _get_schema(schema)
+    nat = _require_native()
+    if isinstance(data, pa.RecordBatch):
+        sa = data.to_struct_array()
+    elif isinstance(data, pa.StructArray):
+        sa = data
+    else:
+        raise TypeError("argument 'data': expected a pyarrow RecordBatch")
+    if not isinstance(num_chunks, int) or isinstance(num_chunks, bool):
+        raise TypeError("argument 'num_chunks': expected int")
+    if num_chunks < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    c_arr = ctypes.create_string_buffer(80)        # struct ArrowArray
+    c_sch = ctypes.create_string_buffer(72)        # struct ArrowSchema
+    sa._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_sch))
+    addrs, stats = nat.encode(comp.capsule, ctypes.addressof(c_arr), ctypes.addressof(c_sch), num_chunks,
+                              device, stream, want_stats)        # releases the two exported structs
+    out = []
+    try:
+        for i, a in enumerate(addrs):
+            out.append(pa.Array._import_from_c(a, pa.binary()))
+            nat.free_struct(a)
+            addrs[i] = 0
+    finally:
+        for a in addrs:
+            if a:
+                nat.release_array(a)
+    return out, stats
+
+
 def serialize_record_batch(data, schema, num_chunks):
-    """src/lib.rs:91-106 (Arrow -> Avro).  Other direction; not part of the GPU decode path yet."""
-    raise NotImplementedError("serialize_record_batch is outside the Avro->Arrow direct-decode path (SURVEY 8f N1)")
+    """src/lib.rs:91-106 -> ruhvro::serialize::serialize_record_batch (serialize.rs:38-67) with the fast encoder
+    (fast_encode.rs:27-53): ``clamp(num_chunks, 1, max(rows, 1))`` BinaryArrays, one Avro datum per row, columns
+    matched to the schema's fields by name.  Runs on the GPU (rh_encode)."""
+    return _encode(data, schema, num_chunks)[0]
 
 
 def serialize_record_batch_spawn(data, schema, num_chunks):
-    """src/lib.rs:130-148."""
-    raise NotImplementedError("serialize_record_batch_spawn is outside the Avro->Arrow direct-decode path (SURVEY 8f N1)")
+    """src/lib.rs:130-148 -- same results as serialize_record_batch (serialize.rs:70-99)."""
+    return _encode(data, schema, num_chunks)[0]
+
+
+def serialize_record_batch_with_stats(data, schema, num_chunks, device: int = -1):
+    """Extension: also returns the engine's per-stage timings (rh_stats)."""
+    return _encode(data, schema, num_chunks, want_stats=True, device=device)
 
 
 def device_count() -> int:
@@ -183,6 +222,7 @@ def device_count() -> int:
 
 __all__ = [
     "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
+    "serialize_record_batch_with_stats",
     "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count", "set_kernel_mode",
     "deserialize_binary_array",
 ]

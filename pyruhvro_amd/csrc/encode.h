@@ -1,0 +1,29 @@
+// Parameters of the Arrow -> Avro encode kernels (encode.hip), shared with the host side (engine_encode.cpp).
+#pragma once
+#include "program.h"
+
+namespace rh {
+
+enum EncErr : uint32_t {
+  EE_ENUM = 100,    // "fast_encode: enum symbol '{sym}' not in schema"   (fast_encode.rs:575-577); pad = op index, detail = row
+  EE_UNION = 101,   // "fast_encode: union type_id {t} out of range"      (fast_encode.rs:540-542); detail = t
+};
+
+struct EParams {
+  uint64_t n;               // rows of the batch
+  uint64_t sz, rows_last;   // rows per chunk / of the last chunk (serialize.rs:19-30)
+  uint32_t k, bpc, nblocks;
+  int32_t nbuf, ndom, list_depth;
+  const Op* prog;           // the decoder's schema program: its buffer ids name the INPUT buffers here
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  const uint64_t* in_ptr;       // [nbuf] device address of every input buffer rebased to logical row 0 (0 = absent)
+  const uint32_t* in_bitoff;    // [nbuf] bit offset of row 0 inside a bitmap's first byte
+  uint32_t* blocksum;           // [nblocks] encoded bytes of every workgroup's rows
+  const uint32_t* blockbase;    // [nblocks] chunk-relative exclusive prefix of blocksum (rh_k_scan)
+  void* const* outptr;          // [k][2]: offsets (i32[rows+1]), data
+  unsigned long long* first_bad;
+  ErrInfo* errinfo;             // [nblocks]
+};
+
+}  // namespace rh

@@ -48,6 +48,9 @@ struct HipError : std::runtime_error {
 struct DecodeError : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+struct ValueClassError : std::runtime_error {   // data-dependent failures of other paths (encode): ValueError in Python
+  using std::runtime_error::runtime_error;
+};
 struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic kernels index that far
 
 #define HIPCHK(expr)                                                                          \
@@ -778,6 +781,9 @@ int guarded(char** err, F&& f) {
   } catch (const DecodeError& e) {
     if (err) *err = dup_msg(e.what());
     return RH_ERR_DECODE;
+  } catch (const ValueClassError& e) {
+    if (err) *err = dup_msg(e.what());
+    return RH_ERR_DECODE;
   } catch (const std::invalid_argument& e) {
     if (err) *err = dup_msg(e.what());
     return RH_ERR_ARGUMENT;
@@ -972,3 +978,391 @@ int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* le
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// Arrow -> Avro: rh_encode
+// ===========================================================================
+#include "encode.h"
+
+extern "C" {
+int rh_launch_esize(const rh::EParams* P, uint32_t lds_bytes, void* stream);
+int rh_launch_eemit(const rh::EParams* P, uint32_t lds_bytes, void* stream);
+uint32_t rh_enc_lds_bytes(int ndom, int list_depth);
+}
+
+namespace {
+
+using EncodeError = ValueClassError;
+
+struct InBuf {            // logical range of one input buffer (host side), rebased to row 0
+  const uint8_t* host = nullptr;
+  uint64_t bytes = 0;
+  uint32_t bitoff = 0;
+};
+
+struct StrSrc {           // where a string / enum node's text lives on the host (for error messages)
+  const int32_t* offsets = nullptr;
+  const uint8_t* data = nullptr;
+};
+
+// Mirrors build_record_encoder / build_field_encoder / build_union_encoder / build_nullable_encoder
+// (ruhvro/src/fast_encode.rs:151-358): walks the Avro type tree, the decoder nodes built from it and the
+// Arrow C Data structs in lockstep, matching record fields to struct children BY NAME.
+struct EncodeBinder {
+  const CompiledSchema& cs;
+  std::vector<InBuf> in;
+  std::vector<StrSrc> strs;   // by node id
+
+  explicit EncodeBinder(const CompiledSchema& c) : cs(c), in(c.bufs.size()), strs(c.nodes.size()) {}
+
+  static const rh::AvroType* null_inner(const rh::AvroType& u) {
+    if (u.variants.size() != 2) return nullptr;
+    if (u.variants[0]->kind == rh::AV_NULL) return u.variants[1].get();
+    if (u.variants[1]->kind == rh::AV_NULL) return u.variants[0].get();
+    return nullptr;
+  }
+
+  void validity(int buf, const ArrowArray* a, int64_t off, int64_t len) {
+    if (buf < 0) return;
+    if (a->n_buffers < 1 || !a->buffers[0] || a->null_count == 0) return;   // absent = all valid
+    in[buf].host = (const uint8_t*)a->buffers[0] + (off >> 3);
+    in[buf].bitoff = (uint32_t)(off & 7);
+    in[buf].bytes = (uint64_t)((in[buf].bitoff + len + 7) >> 3);
+  }
+
+  void bind(const rh::AvroType& t0, int id, const ArrowSchema* fs, const ArrowArray* fa, int64_t off, int64_t len) {
+    const rh::AvroType* t = &t0;
+    if (t->kind == rh::AV_UNION)
+      if (const rh::AvroType* inner = null_inner(*t)) t = inner;     // 2-variant null union: the node is the inner type, nullable
+    const DecNode& n = cs.nodes[id];
+    const std::string fmt = fs->format ? fs->format : "";
+    switch (n.kind) {
+      case rh::NK_NULL:
+        return;
+      case rh::NK_FIXED: {
+        static const char* want[] = {"i", "l", "f", "g", "b"};
+        bool ok = fmt == want[n.fixed];
+        if (t->kind == rh::AV_DATE) ok = fmt == "tdD";
+        if (t->kind == rh::AV_TS_MILLIS) ok = fmt.rfind("tsm:", 0) == 0;
+        if (t->kind == rh::AV_TS_MICROS) ok = fmt.rfind("tsu:", 0) == 0;
+        if (!ok || fa->n_buffers < 2 || (len > 0 && !fa->buffers[1])) throw EncodeError("fast_encode: arrow array downcast failed");
+        InBuf& v = in[n.buf_main];
+        if (n.fixed == rh::FK_BOOL) {
+          v.host = (const uint8_t*)fa->buffers[1] + (off >> 3);
+          v.bitoff = (uint32_t)(off & 7);
+          v.bytes = (uint64_t)((v.bitoff + len + 7) >> 3);
+        } else {
+          const uint64_t w = (n.fixed == rh::FK_I32 || n.fixed == rh::FK_F32) ? 4 : 8;
+          v.host = (const uint8_t*)fa->buffers[1] + (uint64_t)off * w;
+          v.bytes = (uint64_t)len * w;
+        }
+        if (len == 0) v.host = nullptr;
+        if (n.nullable) validity(n.buf_validity, fa, off, len);
+        return;
+      }
+      case rh::NK_STRING:
+      case rh::NK_ENUM: {
+        if (fmt != "u" || fa->n_buffers < 3) throw EncodeError("fast_encode: arrow array downcast failed");
+        if (fa->buffers[1]) {           // an empty array may come without an offsets buffer
+          const int32_t* offs = (const int32_t*)fa->buffers[1] + off;
+          in[n.buf_main].host = (const uint8_t*)offs;
+          in[n.buf_main].bytes = (uint64_t)(len + 1) * 4;
+          const uint64_t dbytes = fa->buffers[2] ? (uint64_t)offs[len] : 0;
+          in[n.buf_data].host = dbytes ? (const uint8_t*)fa->buffers[2] : nullptr;
+          in[n.buf_data].bytes = dbytes;
+          strs[id].offsets = offs;
+          strs[id].data = (const uint8_t*)fa->buffers[2];
+        } else if (len > 0) {
+          throw EncodeError("fast_encode: arrow array downcast failed");
+        }
+        if (n.nullable) validity(n.buf_validity, fa, off, len);
+        return;
+      }
+      case rh::NK_RECORD: {
+        if (fmt != "+s") throw EncodeError("fast_encode: expected StructArray for record");
+        for (size_t i = 0; i < t->fields.size(); i++) {
+          int64_t hit = -1;
+          for (int64_t c = 0; c < fs->n_children; c++)
+            if (fs->children[c]->name && t->fields[i].name == fs->children[c]->name) { hit = c; break; }
+          if (hit < 0) {
+            std::string avail;
+            for (int64_t c = 0; c < fs->n_children; c++) {
+              if (c) avail += ", ";
+              avail += "\"" + std::string(fs->children[c]->name ? fs->children[c]->name : "") + "\"";
+            }
+            throw EncodeError("Arrow struct missing column '" + t->fields[i].name +
+                              "' required by Avro schema. Available columns: [" + avail + "]");
+          }
+          const ArrowArray* ca = fa->children[hit];
+          bind(*t->fields[i].type, n.children[i], fs->children[hit], ca, off + ca->offset, len);
+        }
+        if (n.nullable) validity(n.buf_validity, fa, off, len);
+        return;
+      }
+      case rh::NK_UNION: {
+        if (fmt.rfind("+us:", 0) != 0) {
+          if (fmt.rfind("+ud:", 0) == 0) throw EncodeError("fast_encode: dense unions are not supported (sparse union expected)");
+          throw EncodeError("fast_encode: expected UnionArray for multi-variant union");
+        }
+        const int tb = fa->n_buffers == 1 ? 0 : 1;      // current C data interface: type ids only; older producers put a validity slot first
+        in[n.buf_main].host = len ? (const uint8_t*)fa->buffers[tb] + off : nullptr;
+        in[n.buf_main].bytes = (uint64_t)len;
+        if ((size_t)fa->n_children < t->variants.size()) throw EncodeError("fast_encode: expected UnionArray for multi-variant union");
+        for (size_t i = 0; i < t->variants.size(); i++) {
+          const ArrowArray* ca = fa->children[i];       // schema_translate emits type ids 0..N-1 in variant order
+          bind(*t->variants[i], n.children[i], fs->children[i], ca, off + ca->offset, len);
+        }
+        return;
+      }
+      case rh::NK_LIST:
+      case rh::NK_MAP: {
+        const bool is_map = n.kind == rh::NK_MAP;
+        if (fmt != (is_map ? "+m" : "+l") || fa->n_buffers < 2 || fa->n_children < 1)
+          throw EncodeError(is_map ? "fast_encode: expected MapArray for map schema" : "fast_encode: expected ListArray for array schema");
+        if (fa->buffers[1]) {
+          in[n.buf_main].host = (const uint8_t*)((const int32_t*)fa->buffers[1] + off);
+          in[n.buf_main].bytes = (uint64_t)(len + 1) * 4;
+        } else if (len > 0) {
+          throw EncodeError(is_map ? "fast_encode: expected MapArray for map schema" : "fast_encode: expected ListArray for array schema");
+        }
+        if (n.nullable) validity(n.buf_validity, fa, off, len);
+        const ArrowArray* ca = fa->children[0];
+        const ArrowSchema* csch = fs->children[0];
+        if (is_map) {
+          if (ca->n_children < 2 || csch->n_children < 2) throw EncodeError("fast_encode: expected MapArray for map schema");
+          const ArrowArray* ka = ca->children[0];
+          const ArrowArray* va = ca->children[1];
+          if (std::string(csch->children[0]->format ? csch->children[0]->format : "") != "u")
+            throw EncodeError("fast_encode: map keys must be StringArray");
+          rh::AvroType key_t;
+          key_t.kind = rh::AV_STRING;
+          bind(key_t, n.keys, csch->children[0], ka, ca->offset + ka->offset, ca->length);
+          bind(*t->items, n.children[0], csch->children[1], va, ca->offset + va->offset, ca->length);
+        } else {
+          bind(*t->items, n.children[0], csch, ca, ca->offset, ca->length);
+        }
+        return;
+      }
+    }
+  }
+};
+
+struct BinSlab {          // host memory of the produced BinaryArrays, shared by the k chunks
+  std::atomic<int> refs{0};
+  void* base = nullptr;
+};
+struct BinPriv {
+  const void* buffers[3];
+  BinSlab* slab;
+};
+void release_binary(ArrowArray* a) {
+  if (!a || !a->release) return;
+  BinPriv* p = (BinPriv*)a->private_data;
+  if (p->slab->refs.fetch_sub(1) == 1) {
+    std::free(p->slab->base);
+    delete p->slab;
+  }
+  delete p;
+  a->release = nullptr;
+}
+
+std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, const EncodeBinder& b) {
+  char buf[96];
+  if (e.code == rh::EE_UNION) {
+    std::snprintf(buf, sizeof buf, "fast_encode: union type_id %lld out of range", (long long)e.detail);
+    return buf;
+  }
+  if (e.code == rh::EE_ENUM && e.pad < cs.prog.size()) {
+    const int node = cs.prog[e.pad].node;
+    const StrSrc& s = b.strs[node];
+    std::string sym;
+    if (s.offsets && s.data) sym.assign((const char*)s.data + s.offsets[e.detail], (size_t)(s.offsets[e.detail + 1] - s.offsets[e.detail]));
+    return "fast_encode: enum symbol '" + sym + "' not in schema";
+  }
+  return "encode error";
+}
+
+int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschema, uint64_t num_chunks, const rh_opts* opts,
+                ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats) {
+  const CompiledSchema& cs = *s->cs;
+  Timer total;
+  // schema / batch mismatches are reported before any device work, like the encoder construction of
+  // fast_encode.rs:33-37 that runs before the first row is written
+  EncodeBinder binder(cs);
+  const uint64_t n = (uint64_t)batch->length;
+  binder.bind(*cs.avro, 0, bschema, batch, batch->offset, (int64_t)n);
+
+  require_device();
+  int device = 0;
+  if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
+  else HIPCHK(hipGetDevice(&device));
+  hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
+
+  // chunking of serialize.rs:15-30 (same arithmetic as the decode side)
+  const uint32_t k = rh_clamp_chunks(n, num_chunks);
+  const uint64_t sz = n / k, rows_last = n - (uint64_t)(k - 1) * sz;
+  const uint64_t bpc64 = std::max<uint64_t>((sz + rh::kBlock - 1) / rh::kBlock, 1);
+  const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (rows_last + rh::kBlock - 1) / rh::kBlock;
+  if (nblocks64 > 0x7FFFFFFFull) throw std::invalid_argument("too many rows for one call");
+  const uint32_t nblocks = (uint32_t)nblocks64;
+  const int nbuf = (int)cs.bufs.size();
+  const DeviceProgram& dp = device_program(s, device);
+
+  // ---- inputs -> HBM (every buffer rebased to logical row 0)
+  std::vector<uint64_t> ioff((size_t)nbuf, 0);
+  uint64_t itot = 0;
+  for (int b = 0; b < nbuf; b++) {
+    ioff[b] = itot;
+    itot += align_up(binder.in[b].bytes + 8, kAlign);
+  }
+  Lease din(dev_pool(), std::max<uint64_t>(itot, kAlign), device);
+  Timer th;
+  for (int b = 0; b < nbuf; b++)
+    if (binder.in[b].host && binder.in[b].bytes)
+      HIPCHK(hipMemcpyAsync(din.ptr() + ioff[b], binder.in[b].host, binder.in[b].bytes, hipMemcpyHostToDevice, stream));
+
+  // ---- workspace: [first_bad][totals u64 k] | errinfo | blocksum | blockbase | in_ptr | in_bitoff | outptr
+  const uint64_t o_tot = 16;
+  const uint64_t ctrl_bytes = align_up(o_tot + 8ull * k, kAlign);
+  const uint64_t o_err = ctrl_bytes;
+  const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
+  const uint64_t o_bbase = align_up(o_bsum + 4ull * nblocks, kAlign);
+  const uint64_t o_tab = align_up(o_bbase + 4ull * nblocks, kAlign);
+  const uint64_t tab_bytes = align_up(12ull * std::max(nbuf, 1) + 16ull * k, kAlign);
+  const uint64_t ws_bytes = o_tab + tab_bytes;
+  Lease ws(dev_pool(), ws_bytes, device);
+  Lease hctrl(pin_pool(), ctrl_bytes, device);
+  Lease htab(pin_pool(), tab_bytes, device);
+  HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
+  uint64_t* h_inptr = (uint64_t*)htab.ptr();
+  uint32_t* h_bitoff = (uint32_t*)(htab.ptr() + 8ull * std::max(nbuf, 1));
+  void** h_out = (void**)(htab.ptr() + 12ull * std::max(nbuf, 1) + ((12ull * std::max(nbuf, 1)) % 8 ? 4 : 0));
+  const uint64_t o_out = (uint64_t)((uint8_t*)h_out - htab.ptr());
+  for (int b = 0; b < nbuf; b++) {
+    h_inptr[b] = binder.in[b].host && binder.in[b].bytes ? (uint64_t)(uintptr_t)(din.ptr() + ioff[b]) : 0;
+    h_bitoff[b] = binder.in[b].bitoff;
+  }
+
+  rh::EParams E;
+  std::memset(&E, 0, sizeof E);
+  E.n = n; E.sz = sz; E.rows_last = rows_last; E.k = k; E.bpc = (uint32_t)bpc64; E.nblocks = nblocks;
+  E.nbuf = nbuf; E.ndom = cs.ndom; E.list_depth = cs.list_depth;
+  E.prog = dp.prog; E.sym_off = dp.sym_off; E.sym_data = dp.sym_data;
+  E.in_ptr = (const uint64_t*)(ws.ptr() + o_tab);
+  E.in_bitoff = (const uint32_t*)(ws.ptr() + o_tab + 8ull * std::max(nbuf, 1));
+  E.outptr = (void* const*)(ws.ptr() + o_tab + o_out);
+  E.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
+  E.blockbase = (const uint32_t*)(ws.ptr() + o_bbase);
+  E.first_bad = (unsigned long long*)ws.ptr();
+  E.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
+  // the scan kernel of the decode side, one counter
+  rh::KParams SP;
+  std::memset(&SP, 0, sizeof SP);
+  SP.K = 1; SP.k = k; SP.bpc = (uint32_t)bpc64; SP.nblocks = nblocks;
+  SP.blocksum = E.blocksum; SP.blockbase = (uint32_t*)(ws.ptr() + o_bbase); SP.totals = (uint64_t*)(ws.ptr() + o_tot);
+
+  const uint32_t lds = rh_enc_lds_bytes(cs.ndom, cs.list_depth);
+  auto check_bad = [&](const uint8_t* h) {
+    unsigned long long fb = *(const unsigned long long*)h;
+    if (!fb) return;
+    const uint64_t rec = ~fb;
+    uint64_t c = sz ? std::min<uint64_t>(rec / sz, k - 1) : 0;
+    uint64_t bl = c * bpc64 + (rec - c * sz) / rh::kBlock;
+    rh::ErrInfo ei;
+    HIPCHK(hipMemcpy(&ei, E.errinfo + bl, sizeof ei, hipMemcpyDeviceToHost));
+    throw EncodeError(format_encode_error(ei, cs, binder));
+  };
+
+  // first launch needs the input tables on the device (outptr is filled in later)
+  HIPCHK(hipMemcpyAsync(ws.ptr() + o_tab, htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
+  Events ev;
+  if (stats) ev.init();
+  ev.rec(0, stream);
+  std::vector<uint64_t> totals((size_t)k, 0);
+  if (n > 0) {
+    if (rh_launch_esize(&E, lds, stream)) throw HipError("e_size launch failed");
+    ev.rec(1, stream);
+    if (rh_launch_scan(&SP, stream)) throw HipError("k_scan launch failed");
+    ev.rec(2, stream);
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    check_bad(hctrl.ptr());
+    std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * k);
+  } else {
+    HIPCHK(hipStreamSynchronize(stream));
+    ev.rec(1, stream);
+    ev.rec(2, stream);
+  }
+  const float h2d = th.ms();
+  for (auto t : totals)
+    if (t > 0x7FFFFFFFull) throw EncodeError("offset overflow: a chunk's encoded bytes exceed the 2^31-1 limit of BinaryArray offsets");
+
+  // ---- output arena: per chunk offsets i32[rows+1] + data
+  std::vector<uint64_t> ooff((size_t)k * 2);
+  uint64_t otot = 0, exact = 0;
+  for (uint32_t c = 0; c < k; c++) {
+    const uint64_t rows = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
+    ooff[(size_t)c * 2] = otot;
+    otot += align_up((rows + 1) * 4, kAlign);
+    ooff[(size_t)c * 2 + 1] = otot;
+    otot += align_up(std::max<uint64_t>(totals[c], 8), kAlign);
+    exact += (rows + 1) * 4 + totals[c];
+  }
+  Lease dout(dev_pool(), std::max<uint64_t>(otot, kAlign), device);
+  for (uint32_t c = 0; c < k; c++) {
+    h_out[(size_t)c * 2] = dout.ptr() + ooff[(size_t)c * 2];
+    h_out[(size_t)c * 2 + 1] = dout.ptr() + ooff[(size_t)c * 2 + 1];
+  }
+  HIPCHK(hipMemcpyAsync(ws.ptr() + o_tab + o_out, (uint8_t*)h_out, 16ull * k, hipMemcpyHostToDevice, stream));
+  if (n == 0) HIPCHK(hipMemsetAsync(dout.ptr(), 0, 4, stream));   // offsets[0] of the single empty chunk
+  ev.rec(3, stream);
+  if (n > 0 && rh_launch_eemit(&E, lds, stream)) throw HipError("e_emit launch failed");
+  ev.rec(4, stream);
+  HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), 16, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  check_bad(hctrl.ptr());
+
+  // ---- results -> host, one slab shared by the k BinaryArrays
+  Timer td;
+  BinSlab* slab = new BinSlab();
+  if (posix_memalign(&slab->base, 64, std::max<uint64_t>(otot, 64)) != 0) { delete slab; throw std::bad_alloc(); }
+  hipError_t ce = hipMemcpy(slab->base, dout.ptr(), std::max<uint64_t>(otot, 4), hipMemcpyDeviceToHost);
+  if (ce != hipSuccess) { std::free(slab->base); delete slab; throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(ce)); }
+  slab->refs.store((int)k);
+  for (uint32_t c = 0; c < k; c++) {
+    const uint64_t rows = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
+    BinPriv* p = new BinPriv();
+    p->slab = slab;
+    p->buffers[0] = nullptr;
+    p->buffers[1] = (const uint8_t*)slab->base + ooff[(size_t)c * 2];
+    p->buffers[2] = (const uint8_t*)slab->base + ooff[(size_t)c * 2 + 1];
+    ArrowArray* a = &out_chunks[c];
+    a->length = (int64_t)rows; a->null_count = 0; a->offset = 0;
+    a->n_buffers = 3; a->n_children = 0; a->buffers = p->buffers; a->children = nullptr; a->dictionary = nullptr;
+    a->release = release_binary; a->private_data = p;
+  }
+  if (out_k) *out_k = k;
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->records = n;
+    stats->output_bytes = exact;
+    for (int b = 0; b < nbuf; b++) stats->input_bytes += binder.in[b].bytes;
+    stats->chunks = k;
+    stats->blocks = nblocks;
+    stats->h2d_ms = h2d;
+    stats->size_kernel_ms = ev.ms(0, 1);
+    stats->scan_kernel_ms = ev.ms(1, 2);
+    stats->emit_kernel_ms = ev.ms(3, 4);
+    stats->d2h_ms = td.ms();
+    stats->total_ms = total.ms();
+  }
+  return RH_OK;
+}
+
+}  // namespace
+
+extern "C" int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema, uint64_t num_chunks,
+                         const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
+  if (!s || !batch || !batch_schema || !out_chunks) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] { return encode_impl(const_cast<rh_schema*>(s), batch, batch_schema, num_chunks, opts, out_chunks, out_k, stats); });
+}

@@ -165,6 +165,63 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   return ret;
 }
 
+
+// encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False)
+//   array_addr / schema_addr: ArrowArray / ArrowSchema structs the caller exported the batch's struct array into
+//   (they are released here).  -> (list[int] addresses of malloc'd ArrowArray structs ("z" arrays), stats | None)
+// src/lib.rs:91-106: serialize_record_batch, the GIL is released around the work like py.detach there.
+PyObject* py_encode(PyObject*, PyObject* args) {
+  PyObject* cap;
+  unsigned long long a_addr, s_addr, num_chunks;
+  int device = -1;
+  unsigned long long stream = 0;
+  int want_stats = 0;
+  if (!PyArg_ParseTuple(args, "OKKK|iKp", &cap, &a_addr, &s_addr, &num_chunks, &device, &stream, &want_stats)) return nullptr;
+  ArrowArray* arr = (ArrowArray*)(uintptr_t)a_addr;
+  ArrowSchema* sch = (ArrowSchema*)(uintptr_t)s_addr;
+  auto drop_inputs = [&] {
+    if (arr && arr->release) arr->release(arr);
+    if (sch && sch->release) sch->release(sch);
+  };
+  rh_schema* s = get_schema(cap);
+  if (!s || !arr || !sch) {
+    drop_inputs();
+    if (s) PyErr_SetString(PyExc_ValueError, "encode: null ArrowArray / ArrowSchema");
+    return nullptr;
+  }
+  const uint32_t k = rh_clamp_chunks((uint64_t)arr->length, num_chunks);
+  ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
+  rh_opts opts;
+  opts.device = device;
+  opts.flags = 0;
+  opts.stream = (void*)(uintptr_t)stream;
+  rh_stats st;
+  std::memset(&st, 0, sizeof st);
+  char* err = nullptr;
+  uint32_t out_k = 0;
+  int rc;
+  Py_BEGIN_ALLOW_THREADS
+  rc = rh_encode(s, arr, sch, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+  Py_END_ALLOW_THREADS
+  drop_inputs();
+  if (rc != RH_OK) {
+    std::free(chunks);
+    return raise_from(rc, err);
+  }
+  PyObject* out = PyList_New(out_k);
+  for (uint32_t c = 0; c < out_k; c++) {
+    ArrowArray* one = (ArrowArray*)std::malloc(sizeof(ArrowArray));
+    std::memcpy(one, &chunks[c], sizeof(ArrowArray));
+    PyList_SET_ITEM(out, c, PyLong_FromVoidPtr(one));
+  }
+  std::free(chunks);
+  PyObject* stats = want_stats ? stats_dict(st) : (Py_INCREF(Py_None), Py_None);
+  PyObject* ret = PyTuple_Pack(2, out, stats);
+  Py_DECREF(out);
+  Py_DECREF(stats);
+  return ret;
+}
+
 // release_array(addr): release (if still owned) and free an ArrowArray shell pyarrow did not consume
 PyObject* py_release_array(PyObject*, PyObject* args) {
   PyObject* addr;
@@ -185,6 +242,7 @@ PyMethodDef methods[] = {
     {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
     {"export_schema", py_export_schema, METH_VARARGS, "export_schema(capsule) -> address of ArrowSchema"},
     {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
+    {"encode", py_encode, METH_VARARGS, "encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False)"},
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
     {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},

@@ -1,0 +1,184 @@
+"""GPU parity of the Arrow -> Avro direction: pyruhvro_amd.serialize_record_batch (rh_encode, HIP
+kernels rh_e_size / rh_k_scan / rh_e_emit) vs the encode oracle (oracle/py_encoder.py, the restatement of
+ruhvro/src/fast_encode.rs + serialize.rs), datum for datum, byte for byte.  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import cases
+import random_cases
+from avrogen import fastgen, synth
+from avrogen.schemas import SCHEMAS
+from oracle import c_walker, py_encoder
+
+import pyruhvro_amd as P
+from pyruhvro_amd import cabi
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")
+
+
+def _same(got, exp):
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g.type == pa.binary()
+        g.validate(full=True)
+        assert g.null_count == 0 and g.offset == 0
+        assert g.equals(e), (len(g), len(e))
+        # buffers too: offsets start at 0 and the data buffer holds exactly the datums
+        go = np.frombuffer(g.buffers()[1], dtype=np.int32, count=len(g) + 1)
+        eo = np.frombuffer(e.buffers()[1], dtype=np.int32, count=e.offset + len(e) + 1)[e.offset:]
+        assert np.array_equal(go, eo - eo[0])
+
+
+def _check(batch, schema, k):
+    got = P.serialize_record_batch(batch, schema, k)
+    _same(got, py_encoder.serialize_record_batch(batch, schema, k))
+    return got
+
+
+def _datums(arrays):
+    return [b for a in arrays for b in a.to_pylist()]
+
+
+@pytest.mark.parametrize("name", sorted(synth.GENERATORS))
+def test_generated_records_reencode_byte_for_byte(name):
+    recs = synth.records(name, 1500, seed=11)
+    batch = c_walker.decode(recs, SCHEMAS[name])
+    for k in (1, 4):
+        out = _check(batch, SCHEMAS[name], k)
+        assert _datums(out) == recs            # the generators write the reference's single-block form
+    assert P.serialize_record_batch_spawn(batch, SCHEMAS[name], 3)[0].equals(
+        py_encoder.serialize_record_batch(batch, SCHEMAS[name], 3)[0])
+
+
+def test_golden_datums():
+    g = json.load(open(GOLDEN))
+    for v in g["vectors"]:
+        schema = json.dumps(g["schemas"][v["schema"]])
+        rec = bytes.fromhex(v["hex"])
+        batch = c_walker.decode([rec], schema)
+        out = _check(batch, schema, 1)
+        assert _datums(out) == [rec[: v.get("consumed", len(rec))]], v["name"]
+
+
+@pytest.mark.parametrize("case", cases.nesting_cases() + cases.differential_cases() + cases.wire_cases(), ids=lambda c: c[0])
+def test_nested_and_differential_schemas(case):
+    schema, recs = case[1], case[2]
+    batch = c_walker.decode(recs, schema)
+    for k in (1, 3):
+        _check(batch, schema, k)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_schemas(seed):
+    schema, recs = random_cases.random_case(seed, 300)
+    batch = c_walker.decode(recs, schema)
+    out = _check(batch, schema, 2)
+    # and back through the GPU decoder: decode(encode(x)) == x
+    back = P.deserialize_array(_datums(out), schema)
+    assert back.equals(batch)
+
+
+def test_round_trip_through_both_gpu_directions():
+    recs = synth.records("full", 20000, seed=3)
+    batches = P.deserialize_array_threaded(recs, SCHEMAS["full"], 5)
+    out = []
+    for b in batches:
+        out += _datums(P.serialize_record_batch(b, SCHEMAS["full"], 2))
+    assert out == recs
+
+
+def test_columns_matched_by_name_and_reference_error_texts():
+    recs = synth.records("cfg3", 300)
+    batch = c_walker.decode(recs, SCHEMAS["cfg3"])
+    order = (4, 2, 0, 3, 1)
+    shuffled = pa.RecordBatch.from_arrays([batch.column(i) for i in order], names=[batch.schema.names[i] for i in order])
+    assert _datums(P.serialize_record_batch(shuffled, SCHEMAS["cfg3"], 2)) == recs      # fast_encode.rs:155-181
+    extra = shuffled.append_column("unused", pa.array(range(300)))
+    assert _datums(P.serialize_record_batch(extra, SCHEMAS["cfg3"], 2)) == recs
+    with pytest.raises(ValueError) as ei:
+        P.serialize_record_batch(batch.drop_columns(["age"]), SCHEMAS["cfg3"], 1)
+    assert str(ei.value) == ("Arrow struct missing column 'age' required by Avro schema. "
+                             'Available columns: ["id", "name", "s", "class"]')
+
+
+def test_data_dependent_errors_carry_the_reference_text_and_lowest_row_wins():
+    s = SCHEMAS["t_enum"]
+    syms = ["A"] * 700
+    syms[431] = "Z"
+    syms[650] = "QQ"
+    bad = pa.RecordBatch.from_arrays([pa.array(syms)], names=["e"])
+    for k in (1, 3):
+        with pytest.raises(ValueError) as ei:
+            P.serialize_record_batch(bad, s, k)
+        assert str(ei.value) == "fast_encode: enum symbol 'Z' not in schema"        # fast_encode.rs:575-577
+        with pytest.raises(ValueError) as eo:
+            py_encoder.serialize_record_batch(bad, s, k)
+        assert str(eo.value) == str(ei.value)
+    su = SCHEMAS["t_union"]
+    batch = c_walker.decode(cases._enc(su, [{"u": None}, {"u": "x"}] * 200), su)
+    u = batch.column(0)
+    ids = np.frombuffer(u.buffers()[1], dtype=np.int8, count=len(u)).copy()
+    ids[333] = 9
+    ids[390] = -3
+    broken = pa.UnionArray.from_sparse(pa.array(ids, type=pa.int8()), [u.field(i) for i in range(u.type.num_fields)],
+                                       field_names=[u.type.field(i).name for i in range(u.type.num_fields)])
+    with pytest.raises(ValueError) as ei:
+        P.serialize_record_batch(pa.RecordBatch.from_arrays([broken], names=["u"]), su, 2)
+    assert str(ei.value) == "fast_encode: union type_id 9 out of range"          # fast_encode.rs:540-542
+
+
+def test_chunking_and_empty_batches():
+    recs = synth.records("flat4", 7)
+    batch = c_walker.decode(recs, SCHEMAS["flat4"])
+    for k, want in ((1, [7]), (3, [2, 2, 3]), (0, [7]), (50, [1] * 7)):
+        got = _check(batch, SCHEMAS["flat4"], k)
+        assert [len(a) for a in got] == want                                     # serialize.rs:15-30
+    empty = c_walker.decode([], SCHEMAS["flat4"])
+    got = _check(empty, SCHEMAS["flat4"], 4)
+    assert [len(a) for a in got] == [0]
+
+
+@pytest.mark.parametrize("name", ["full", "cfg3", "array_and_map", "nullable_primitives", "nested_struct"])
+def test_sliced_inputs_honour_every_offset(name):
+    """A sliced batch has non-zero offsets on the struct, its children and (for bitmaps) non-byte-aligned bit
+    offsets: value(row) in the reference applies them all."""
+    recs = synth.records(name, 1000, seed=5)
+    batch = c_walker.decode(recs, SCHEMAS[name])
+    for lo, ln in ((1, 999), (13, 700), (511, 3), (999, 1), (1000, 0)):
+        part = batch.slice(lo, ln)
+        out = _check(part, SCHEMAS[name], 3)
+        assert _datums(out) == recs[lo: lo + ln]
+
+
+def test_non_nullable_leaves_ignore_validity_and_nulls_under_null_parents_are_skipped():
+    """fast_encode.rs:391-399: Int/Long/... write value(row) whatever the validity bit says."""
+    s = json.dumps({"type": "record", "name": "r", "fields": [{"name": "a", "type": "long"},
+                                                               {"name": "b", "type": ["null", "string"]}]})
+    a = pa.array([1, None, 3, None], type=pa.int64())
+    b = pa.array(["x", None, "", "zz"])
+    rb = pa.RecordBatch.from_arrays([a, b], names=["a", "b"])
+    _check(rb, s, 1)
+
+
+def test_large_batch_matches_generator_bytes():
+    """BASELINE config-4 shape at 1M rows: encode(decode(records)) == records, checked through the packed payload."""
+    n = 1_000_000
+    data, offsets = fastgen.generate("full", n)
+    batches = cabi.decode_packed(data, offsets, SCHEMAS["full"], 1)
+    out, st = P.serialize_record_batch_with_stats(batches[0], SCHEMAS["full"], 8)
+    assert [len(a) for a in out] == [n // 8] * 8
+    pos = 0
+    for a in out:
+        o = np.frombuffer(a.buffers()[1], dtype=np.int32, count=len(a) + 1)
+        d = np.frombuffer(a.buffers()[2], dtype=np.uint8, count=int(o[-1]))
+        r0 = pos
+        pos += len(a)
+        assert np.array_equal(o.astype(np.uint64), offsets[r0: pos + 1] - offsets[r0])
+        assert np.array_equal(d, data[int(offsets[r0]): int(offsets[pos])])
+    assert st["records"] == n and st["emit_kernel_ms"] > 0

@@ -146,7 +146,7 @@ def test_argument_errors_without_touching_the_gpu():
         P.deserialize_array_threaded([b"\x00"], 123, 2)
     with pytest.raises(ValueError):
         P.deserialize_array_threaded([b"\x00"], "{", 2)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):
         P.serialize_record_batch(None, SCHEMAS["flat4"], 1)
     assert set(["deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
                 "serialize_record_batch", "serialize_record_batch_spawn"]) <= set(dir(P))   # src/lib.rs:150-158
@@ -176,3 +176,33 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle_walk" not in txt, f
+
+
+def test_encode_binding_rejects_mismatched_batches_before_any_device_work():
+    """rh_encode walks schema and batch together first (encoder construction, fast_encode.rs:151-358): columns are
+    matched by name, Arrow types are checked, and the reference's messages come back as ValueError."""
+    import pyarrow as pa
+    s = SCHEMAS["flat4"]
+    rb = pa.RecordBatch.from_arrays([pa.array([1], pa.int32()), pa.array([2], pa.int64()), pa.array([0.5]), pa.array([True])],
+                                    names=["i", "l", "d", "b"])
+    with pytest.raises(ValueError) as ei:
+        P.serialize_record_batch(rb.drop_columns(["d"]), s, 1)
+    assert str(ei.value) == ("Arrow struct missing column 'd' required by Avro schema. "
+                             'Available columns: ["i", "l", "b"]')                     # fast_encode.rs:173-177
+    wrong = rb.set_column(0, "i", pa.array([1], pa.int64()))
+    with pytest.raises(ValueError) as ei:
+        P.serialize_record_batch(wrong, s, 1)
+    assert str(ei.value) == "fast_encode: arrow array downcast failed"
+    with pytest.raises(ValueError):
+        P.serialize_record_batch(rb, "{", 1)
+    with pytest.raises(TypeError):
+        P.serialize_record_batch(rb, s, "2")
+    with pytest.raises(OverflowError):
+        P.serialize_record_batch_spawn(rb, s, -1)
+    su = SCHEMAS["t_union"]
+    with pytest.raises(ValueError) as ei:
+        P.serialize_record_batch(pa.RecordBatch.from_arrays([pa.array(["x"])], names=["u"]), su, 1)
+    assert str(ei.value) == "fast_encode: expected UnionArray for multi-variant union"   # fast_encode.rs:261-263
+    if not has_gpu():
+        with pytest.raises(RuntimeError):          # a matching batch then needs the device: no CPU fallback
+            P.serialize_record_batch(rb, s, 1)
