@@ -122,9 +122,10 @@ void rh_device_result_free(rh_device_result* r);
 
 /* Schema-specialised kernel management.  rh_schema_kernel_source returns the generated HIP source
  * (malloc'd, release with rh_free_string).  rh_schema_prebuild generates, compiles (hiprtc, gfx950;
- * needs no GPU) and stores the code object in the kernel cache so later processes only load it;
- * returns 0 and sets *cached = 1 when it was already there. */
+ * needs no GPU) and stores the code objects (decode pair and encode pair) in the kernel cache so later
+ * processes only load them; returns 0 and sets *cached = 1 when both were already there. */
 char* rh_schema_kernel_source(const rh_schema* s);
+char* rh_schema_encode_kernel_source(const rh_schema* s);      /* the Arrow -> Avro pair (rh_encode) */
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err);
 
 /* Arrow -> Avro, the other direction.  Replaces ruhvro::serialize::serialize_record_batch

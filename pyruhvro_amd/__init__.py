@@ -185,7 +185,7 @@ def _encode(data, schema: str, num_chunks: int, want_stats: bool = False, device
     c_sch = ctypes.create_string_buffer(72)        # struct ArrowSchema
     sa._export_to_c(ctypes.addressof(c_arr), ctypes.addressof(c_sch))
     addrs, stats = nat.encode(comp.capsule, ctypes.addressof(c_arr), ctypes.addressof(c_sch), num_chunks,
-                              device, stream, want_stats)        # releases the two exported structs
+                              device, stream, want_stats, _kernel_mode)   # releases the two exported structs
     out = []
     try:
         for i, a in enumerate(addrs):

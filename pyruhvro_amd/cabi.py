@@ -87,6 +87,8 @@ def lib():
         L.rh_free_string.argtypes = [C.c_void_p]
         L.rh_schema_kernel_source.restype = C.c_void_p
         L.rh_schema_kernel_source.argtypes = [C.c_void_p]
+        L.rh_schema_encode_kernel_source.restype = C.c_void_p
+        L.rh_schema_encode_kernel_source.argtypes = [C.c_void_p]
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_device_count.restype = C.c_int
@@ -147,6 +149,18 @@ def kernel_source(schema_json: str) -> str:
     p = L.rh_schema_kernel_source(Schema.get(schema_json).handle)
     if not p:
         raise RuntimeError("rh_schema_kernel_source failed")
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.rh_free_string(p)
+
+
+def encode_kernel_source(schema_json: str) -> str:
+    """HIP source of the schema-specialised Arrow -> Avro kernels (rh_schema_encode_kernel_source)."""
+    L = lib()
+    p = L.rh_schema_encode_kernel_source(Schema.get(schema_json).handle)
+    if not p:
+        raise RuntimeError("rh_schema_encode_kernel_source failed")
     try:
         return C.string_at(p).decode()
     finally:

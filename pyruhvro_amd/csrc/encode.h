@@ -22,6 +22,8 @@ struct EParams {
   uint32_t* blocksum;           // [nblocks] encoded bytes of every workgroup's rows
   const uint32_t* blockbase;    // [nblocks] chunk-relative exclusive prefix of blocksum (rh_k_scan)
   void* const* outptr;          // [k][2]: offsets (i32[rows+1]), data
+  uint32_t* rowlen;             // [nblocks*256] encoded length of every row: written by rh_e_size, read by rh_e_emit
+  uint32_t win_bytes;           // rh_e_emit: LDS bytes of the output staging window (0 = always store straight to HBM)
   unsigned long long* first_bad;
   ErrInfo* errinfo;             // [nblocks]
 };

@@ -1,0 +1,440 @@
+// Arrow -> Avro encode on CDNA4 (gfx950): the per-row walk, shared by the generic schema-program interpreter
+// (encode.hip) and the schema-specialised kernels that specialize.cpp generates and hiprtc compiles.
+//
+// Reference: ruhvro/src/fast_encode.rs:387-599 (per-row write of every encoder variant, zig-zag varints, one block
+// per array/map) and ruhvro/src/serialize.rs:19-67 (chunking).  One lane = one row of the batch, one workgroup =
+// 256 consecutive rows of one output chunk.  The schema program is the decoder's (program.h); its buffer ids name
+// the INPUT Arrow buffers here, every one rebased to logical row 0 by the host (engine.cpp, EncodeBinder).
+//
+// Every node is handled in two halves so that the specialised kernels can issue the loads of many fields before
+// the first byte is produced (the walk is bound by dependent-load latency, not by bytes):
+//   e_*_load   what the node needs from its input buffers at the lane's current row -- UNCONDITIONAL loads: every
+//              lane, present or not, reads a valid address (the host pads every buffer, points absent validity
+//              bitmaps at an all-ones bitmap, and row cursors never leave [0, rows]);
+//   e_*_put    fast_encode.rs's write for that node, predicated on the lane being present.
+#pragma once
+#include "encode.h"
+#include "kernel_common.h"
+
+namespace rh {
+
+#define RH_LDS __attribute__((address_space(3)))   // typed LDS pointers: ds_* instructions, never flat_*
+
+constexpr int M_SIZE = 0, M_DIRECT = 1, M_STAGED = 2;   // what a walk does with the bytes it produces
+
+struct ELane {
+  uint32_t len;        // bytes produced so far by this row (size pass: counted; emit pass: cursor)
+  uint32_t err;
+  int64_t edetail;
+  uint32_t eop;
+  bool live, pres;
+  uint32_t pstk, lstk;
+  uint64_t sstk;
+  __device__ __forceinline__ bool writes() const { return live && pres && err == 0; }
+};
+
+struct FixedV { uint64_t bits; bool valid; };      // raw value (ints sign-extended to 64 bits), validity bit
+struct SpanV { uint32_t s0, s1; bool valid; };     // offsets[row], offsets[row+1], validity bit
+
+
+// ---- byte sinks ------------------------------------------------------------------------------------------------
+template <int MODE, class Ctx>
+__device__ __forceinline__ void put_byte(const Ctx& c, ELane& L, uint8_t b) {
+  if (MODE == M_DIRECT) c.out[L.len] = b;
+  if (MODE == M_STAGED) c.lout[L.len] = b;
+  L.len++;
+}
+
+// write_zigzag_long, fast_encode.rs:583-591
+template <int MODE, class Ctx>
+__device__ __forceinline__ void put_varint(const Ctx& c, ELane& L, int64_t v) {
+  uint64_t zz = ((uint64_t)v << 1) ^ (uint64_t)(v >> 63);
+  if (MODE == M_SIZE) {                       // bytes = ceil(significant bits / 7), at least 1
+    const uint32_t bits = 64u - (uint32_t)__builtin_clzll(zz | 1ull);
+    L.len += (bits + 6u) / 7u;
+    return;
+  }
+  for (;;) {
+    const bool more = (zz & ~0x7Full) != 0;
+    put_byte<MODE>(c, L, (uint8_t)((zz & 0x7F) | (more ? 0x80 : 0)));
+    if (!more) break;
+    zz >>= 7;
+  }
+}
+
+// N little-endian bytes of a register (float / double payloads, fast_encode.rs:419-431)
+template <int MODE, int N, class Ctx>
+__device__ __forceinline__ void put_raw(const Ctx& c, ELane& L, uint64_t bits) {
+  if (MODE == M_DIRECT) {
+    if (N == 4) *reinterpret_cast<RH_GLOBAL u32u*>(c.out + L.len) = (uint32_t)bits;
+    else *reinterpret_cast<RH_GLOBAL u64u*>(c.out + L.len) = bits;
+  }
+  if (MODE == M_STAGED) {
+    RH_LDS uint8_t* d = c.lout + L.len;
+    if (((uint32_t)(uintptr_t)d & 3u) == 0) {          // aligned dwords when the cursor allows it, bytes otherwise
+      volatile RH_LDS uint32_t* dw = reinterpret_cast<volatile RH_LDS uint32_t*>(d);   // volatile: two dword stores, not one b64
+      dw[0] = (uint32_t)bits;
+      if (N == 8) dw[1] = (uint32_t)(bits >> 32);
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; j++) d[j] = (uint8_t)(bits >> (8 * j));
+    }
+  }
+  L.len += N;
+}
+
+// m <= 32 bytes held in w[0..8) (w[8] = 0) -> LDS at D, any alignment, exactly m bytes: byte head up to the next
+// dword boundary, aligned dwords funnel-shifted out of the register stream (v_alignbyte), byte tail.  LDS wants
+// aligned accesses -- unaligned DS accesses are serviced one lane per cycle on this part.
+__device__ __forceinline__ void lds_put_32(RH_LDS uint8_t* D, const uint32_t (&w)[9], uint32_t m) {
+  const uint32_t h0 = (4u - ((uint32_t)(uintptr_t)D & 3u)) & 3u;
+  const uint32_t h = h0 < m ? h0 : m;
+  if (h > 0) D[0] = (uint8_t)w[0];
+  if (h > 1) D[1] = (uint8_t)(w[0] >> 8);
+  if (h > 2) D[2] = (uint8_t)(w[0] >> 16);
+  const uint32_t q = (m - h) >> 2, t = (m - h) & 3u;
+  volatile RH_LDS uint32_t* Dw = reinterpret_cast<volatile RH_LDS uint32_t*>(D + h);   // volatile: keep them dword stores
+  uint32_t xt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t x = __builtin_amdgcn_alignbyte(w[k + 1], w[k], h);        // stream bytes [4k+h, 4k+h+4)
+    if ((uint32_t)k < q) Dw[k] = x;
+    if ((uint32_t)k == q) xt = x;
+  }
+  RH_LDS uint8_t* Dt = D + h + 4u * q;
+  if (t > 0) Dt[0] = (uint8_t)xt;
+  if (t > 1) Dt[1] = (uint8_t)(xt >> 8);
+  if (t > 2) Dt[2] = (uint8_t)(xt >> 16);
+}
+
+// first 32 bytes at s (any alignment; the host pads every data buffer so the over-read stays inside the arena)
+__device__ __forceinline__ void ld_32(const RH_GLOBAL uint8_t* s, uint32_t (&w)[9]) {
+  const v4w a = *reinterpret_cast<const RH_GLOBAL v4wu*>(s);
+  const v4w b = *reinterpret_cast<const RH_GLOBAL v4wu*>(s + 16);
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = 0;
+}
+
+template <int MODE, class Ctx>
+__device__ __forceinline__ void put_bytes(const Ctx& c, ELane& L, const RH_GLOBAL uint8_t* s, uint32_t n) {
+  if (MODE == M_DIRECT) {
+    RH_GLOBAL uint8_t* d = c.out + L.len;
+    uint32_t j = 0;
+    for (; j + 8 <= n; j += 8) *reinterpret_cast<RH_GLOBAL u64u*>(d + j) = *reinterpret_cast<const RH_GLOBAL u64u*>(s + j);
+    for (; j < n; j++) d[j] = s[j];
+  }
+  if (MODE == M_STAGED) {       // 32 bytes per round trip to HBM: two 16-byte loads in flight, then register -> LDS
+    RH_LDS uint8_t* d = c.lout + L.len;
+    for (uint32_t j = 0; j < n; j += 32) {
+      uint32_t w[9];
+      ld_32(s + j, w);
+      const uint32_t m = n - j;
+      lds_put_32(d + j, w, m < 32u ? m : 32u);
+    }
+  }
+  L.len += n;
+}
+
+// write_nullable (563-572): branch index for a null / a value -- zig-zag of 0 or 1 is one byte
+template <int MODE, class Ctx>
+__device__ __forceinline__ void put_branch(const Ctx& c, ELane& L, bool is_null, bool null_first) {
+  put_byte<MODE>(c, L, (uint8_t)((is_null != null_first) ? 2 : 0));
+}
+
+// ---- loads -----------------------------------------------------------------------------------------------------
+template <class Ctx>
+__device__ __forceinline__ bool ld_bit(const Ctx& c, int buf, uint32_t r) {      // validity / boolean value of logical row r
+  const uint32_t b = r + c.bitoff(buf);
+  return (reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(buf))[b >> 3] >> (b & 7)) & 1;
+}
+
+template <class Ctx>
+__device__ __forceinline__ FixedV e_fixed_load(const Ctx& c, const Op op) {
+  const uint32_t r = c.row(op.dom);
+  FixedV v;
+  v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
+  if (op.a == FK_I32) v.bits = (uint64_t)(int64_t)reinterpret_cast<const RH_GLOBAL int32_t*>(c.in(op.buf1))[r];
+  else if (op.a == FK_F32) v.bits = reinterpret_cast<const RH_GLOBAL uint32_t*>(c.in(op.buf1))[r];
+  else if (op.a == FK_BOOL) v.bits = ld_bit(c, op.buf1, r) ? 1 : 0;
+  else v.bits = reinterpret_cast<const RH_GLOBAL uint64_t*>(c.in(op.buf1))[r];
+  return v;
+}
+
+template <class Ctx>
+__device__ __forceinline__ SpanV e_span_load(const Ctx& c, const Op op) {        // string / enum / list / map offsets
+  const uint32_t r = c.row(op.dom);
+  SpanV v;
+  v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
+  const RH_GLOBAL uint32_t* off = reinterpret_cast<const RH_GLOBAL uint32_t*>(c.in(op.buf1));
+  v.s0 = off[r];
+  v.s1 = off[r + 1];
+  return v;
+}
+
+template <class Ctx>
+__device__ __forceinline__ bool e_rec_load(const Ctx& c, const Op op) { return ld_bit(c, op.buf0, c.row(op.dom)); }
+
+template <class Ctx>
+__device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op) {
+  return reinterpret_cast<const RH_GLOBAL int8_t*>(c.in(op.buf1))[c.row(op.dom)];
+}
+
+// ---- writes ----------------------------------------------------------------------------------------------------
+// fast_encode.rs:391-399, 407-455
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_fixed_put(const Ctx& c, ELane& L, const Op op, const FixedV v) {
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  if (op.a == FK_I32 || op.a == FK_I64) put_varint<MODE>(c, L, (int64_t)v.bits);
+  else if (op.a == FK_F32) put_raw<MODE, 4>(c, L, v.bits);
+  else if (op.a == FK_F64) put_raw<MODE, 8>(c, L, v.bits);
+  else put_byte<MODE>(c, L, (uint8_t)(v.bits & 1));
+}
+
+// write_string, fast_encode.rs:593-597
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_string_put(const Ctx& c, ELane& L, const Op op, const SpanV v) {
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  const uint32_t n = v.s1 - v.s0;
+  put_varint<MODE>(c, L, (int64_t)n);
+  put_bytes<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0, n);
+}
+
+// symbol text -> index by comparing against the schema's symbol table in HBM (any symbol length)
+struct EnumTableFinder {
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  int32_t first, count;
+  __device__ __forceinline__ int32_t operator()(const RH_GLOBAL uint8_t* sp, uint32_t n) const {
+    int32_t found = -1;
+    for (int32_t s = 0; s < count && found < 0; s++) {
+      const uint32_t a = sym_off[first + s], b = sym_off[first + s + 1];
+      if (b - a != n) continue;
+      bool eq = true;
+      for (uint32_t j = 0; j < n && eq; j++) eq = sp[j] == sym_data[a + j];
+      if (eq) found = s;
+    }
+    return found;
+  }
+};
+
+// write_enum_idx, fast_encode.rs:574-581.  find(sp, n) -> symbol index or -1.
+template <int MODE, class Ctx, class Find>
+__device__ __forceinline__ void e_enum_put(const Ctx& c, ELane& L, const Op op, const SpanV v, int pc, const Find& find) {
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  const int32_t found = find(reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0, v.s1 - v.s0);
+  if (found < 0) { L.err = EE_ENUM; L.eop = (uint32_t)pc; L.edetail = c.row(op.dom); }
+  else put_varint<MODE>(c, L, found);
+}
+
+// NullableRecord, 465-476: the struct's own validity
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_rec_begin(const Ctx& c, ELane& L, const Op op, const bool valid) {
+  const bool wr = L.writes();
+  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
+  if (wr) put_branch<MODE>(c, L, !valid, (op.flags & F_NULL_FIRST) != 0);
+  L.pres = wr && valid;
+}
+__device__ __forceinline__ void e_rec_end(ELane& L) {
+  L.pres = L.pstk & 1;
+  L.pstk >>= 1;
+}
+
+// UnionEncoder::write, 507-521 (sparse: children share the row)
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_union_begin(const Ctx& c, ELane& L, const Op op, const int32_t t, int pc) {
+  const bool wr = L.writes();
+  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
+  L.sstk = (L.sstk << 8) | 0xFFull;
+  if (wr) {
+    if (t < 0 || t >= op.a) { L.err = EE_UNION; L.eop = (uint32_t)pc; L.edetail = t; }
+    else {
+      put_varint<MODE>(c, L, t);
+      L.sstk = (L.sstk & ~0xFFull) | (uint64_t)t;
+    }
+  }
+}
+__device__ __forceinline__ void e_variant(ELane& L, const Op op) {
+  L.pres = (L.pstk & 1) && ((uint32_t)(L.sstk & 0xFF) == (uint32_t)op.a);
+}
+__device__ __forceinline__ void e_union_end(ELane& L) {
+  L.pres = L.pstk & 1;
+  L.pstk >>= 1;
+  L.sstk >>= 8;
+}
+
+// ListEncoder / MapEncoder::write, 525-561 (+ Nullable*, 478-496)
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_list_begin(Ctx& c, ELane& L, const Op op, const SpanV v) {
+  const bool wr = L.writes();
+  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
+  L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
+  uint32_t n = 0;
+  bool has = false;
+  if (wr) {
+    if (op.flags & F_NULLABLE) put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (v.valid) {
+      n = v.s1 - v.s0;
+      if (n > 0) put_varint<MODE>(c, L, (int64_t)n);
+      c.set_row(op.a, v.s0);            // op.a = child row domain: first item
+      has = true;
+    }
+  }
+  c.set_rem(op.c, n);
+  // lstk bit 0 remembers "this lane owes a 0 terminator"; the saved `live` sits one bit above it
+  L.lstk = (L.lstk << 1) | (has ? 1u : 0u);
+  L.live = has;
+  L.pres = has;
+}
+template <class Ctx>
+__device__ __forceinline__ bool e_list_next(const Ctx& c, ELane& L, const Op op) {   // false: no lane has an item left
+  const bool item = L.live && L.err == 0 && c.rem(op.c) > 0;
+  L.pres = item;
+  return __any(item);
+}
+template <class Ctx>
+__device__ __forceinline__ void e_list_tail(Ctx& c, ELane& L, const Op op) {
+  const uint32_t left = c.rem(op.c);
+  if (L.live && L.err == 0 && left > 0) {
+    c.set_rem(op.c, left - 1);
+    c.set_row(op.a, c.row(op.a) + 1);
+  }
+}
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_list_end(const Ctx& c, ELane& L) {
+  const bool owes = (L.lstk & 1) != 0;
+  L.lstk >>= 1;
+  L.live = L.lstk & 1;
+  L.lstk >>= 1;
+  L.pres = L.pstk & 1;
+  L.pstk >>= 1;
+  if (owes && L.live && L.err == 0) put_byte<MODE>(c, L, 0);    // terminator (an empty list is just this 0)
+}
+
+// ---- workgroup frame -------------------------------------------------------------------------------------------
+__device__ __forceinline__ Geo egeometry(const EParams& P, uint32_t b) {
+  Geo g;
+  uint32_t chunk = b / P.bpc;
+  if (chunk > P.k - 1) chunk = P.k - 1;
+  const uint32_t lb = b - chunk * P.bpc;
+  const uint64_t rows_c = chunk == P.k - 1 ? P.rows_last : P.sz;
+  g.chunk = chunk;
+  g.lrow0 = lb * kBlock;
+  g.rec0 = (uint64_t)chunk * P.sz + g.lrow0;
+  const uint64_t left = rows_c - g.lrow0;
+  g.nrec = left < (uint64_t)kBlock ? (uint32_t)left : (uint32_t)kBlock;
+  return g;
+}
+
+__device__ __forceinline__ void elane_init(ELane& L, const Geo& g, uint32_t tid) {
+  L.len = 0; L.err = 0; L.edetail = 0; L.eop = 0;
+  L.live = tid < g.nrec; L.pres = L.live;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0;
+}
+
+// misc[0] lowest erroring tid, misc[4..7] wave totals
+__device__ __forceinline__ void ereport(const EParams& P, uint32_t* misc, const ELane& L, const Geo& g, uint32_t tid) {
+  if (L.err) atomicMin(&misc[0], tid);
+  __syncthreads();
+  if (misc[0] == tid) {
+    ErrInfo ei; ei.code = L.err; ei.pad = L.eop; ei.detail = L.edetail;
+    P.errinfo[blockIdx.x] = ei;
+    atomicMax(P.first_bad, ~(unsigned long long)(g.rec0 + tid));
+  }
+}
+
+// W: the walker.  W::Ctx is its lane context, W::kCursorWords(P) the LDS words its row cursors take in front of
+// misc[8] (0 when they live in registers), W::walk<MODE>(c, L) the per-row walk.
+//
+//   size: walk 1, the encoded length of every row -> rowlen[], per-workgroup sums, first failing row
+template <class W>
+__device__ __forceinline__ void e_size_body(const EParams& P, uint8_t* smem) {
+  uint32_t* cursors = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* misc = cursors + W::cursor_words(P);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Geo g = egeometry(P, blockIdx.x);
+  if (tid == 0) misc[0] = 0xFFFFFFFFu;
+  ELane L;
+  elane_init(L, g, tid);
+  typename W::Ctx c;
+  W::init(c, P, cursors, g, tid);
+  __syncthreads();
+  W::template walk<M_SIZE>(c, L);
+  const uint32_t mylen = tid < g.nrec ? L.len : 0u;
+  P.rowlen[(size_t)blockIdx.x * kBlock + tid] = mylen;
+  const uint32_t v = wave_sum(mylen);
+  if (lane == 0) misc[4 + wave] = v;
+  ereport(P, misc, L, g, tid);     // barrier inside
+  if (tid == 0) P.blocksum[blockIdx.x] = misc[4] + misc[5] + misc[6] + misc[7];
+}
+
+//   emit: row lengths back from the size pass, scan inside the workgroup, offsets[row+1], then walk 2 writes the
+//   datum bytes -- into an LDS window laid out congruent (mod 16) to the workgroup's contiguous output range, which
+//   the whole workgroup then streams to HBM with aligned 16-byte stores.  A workgroup whose rows do not fit the
+//   window stores straight to HBM (per-lane byte stores).
+template <class W>
+__device__ __forceinline__ void e_emit_body(const EParams& P, uint8_t* smem) {
+  uint32_t* cursors = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* misc = cursors + W::cursor_words(P);
+  uint8_t* const window = reinterpret_cast<uint8_t*>(misc + 8);        // 16-byte aligned
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Geo g = egeometry(P, blockIdx.x);
+  ELane L;
+  elane_init(L, g, tid);
+  typename W::Ctx c;
+  W::init(c, P, cursors, g, tid);
+  const uint32_t mylen = P.rowlen[(size_t)blockIdx.x * kBlock + tid];   // 0 beyond the chunk's rows
+  const uint32_t incl = wave_incl_scan(mylen, lane);
+  if (lane == 63) misc[4 + wave] = incl;
+  __syncthreads();
+  const uint32_t base = P.blockbase[blockIdx.x];                        // chunk-relative first byte of this workgroup
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; w++) {
+    const uint32_t t = misc[4 + w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  const uint32_t rel = before + incl - mylen;                           // first byte of this row inside the workgroup's range
+  RH_GLOBAL int32_t* offs = reinterpret_cast<RH_GLOBAL int32_t*>(reinterpret_cast<uintptr_t>(P.outptr[(size_t)g.chunk * 2]));
+  RH_GLOBAL uint8_t* data = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(P.outptr[(size_t)g.chunk * 2 + 1]));
+  if (tid < g.nrec) offs[g.lrow0 + tid + 1] = (int32_t)(base + rel + mylen);
+  if (g.lrow0 == 0 && tid == 0) offs[0] = 0;
+
+  const uint32_t shift = base & 15u;          // data is 256-byte aligned: LDS window offset == HBM address (mod 16)
+  c.out = data + base + rel;
+  c.lout = (RH_LDS uint8_t*)(window + shift + rel);
+  if (shift + total > P.win_bytes) {          // uniform: this workgroup's rows do not fit the window
+    W::template walk<M_DIRECT>(c, L);
+    return;
+  }
+  W::template walk<M_STAGED>(c, L);
+  __syncthreads();
+  // window[shift, shift+total) -> data[base, base+total): byte head up to the first 16-byte boundary, aligned
+  // 16-byte body (ds_read_b128 -> global_store_dwordx4, consecutive lanes = consecutive lines), byte tail
+  RH_GLOBAL uint8_t* dst = data + base;
+  uint32_t head = (16u - shift) & 15u;
+  if (head > total) head = total;
+  if (tid < head) dst[tid] = window[shift + tid];
+  const uint32_t nvec = (total - head) >> 4;
+  const v4u* src16 = reinterpret_cast<const v4u*>(window + shift + head);
+  RH_GLOBAL v4u* dst16 = reinterpret_cast<RH_GLOBAL v4u*>(dst + head);
+  for (uint32_t i = tid; i < nvec; i += kBlock) dst16[i] = src16[i];
+  const uint32_t done = head + (nvec << 4);
+  if (tid < total - done) dst[done + tid] = window[shift + done + tid];
+}
+
+// LDS bytes in front of rh_e_emit's staging window: cursor words of the walker + misc[8]
+__host__ __device__ inline uint32_t enc_lds_fixed_bytes(uint32_t cursor_words) { return (cursor_words + 8) * 4; }
+
+}  // namespace rh

@@ -205,6 +205,7 @@ struct rh_schema {
   std::mutex mu;
   std::map<int, DeviceProgram> dev;
   std::map<int, SpecKernel> spec;
+  std::map<int, SpecKernel> espec;   // Arrow -> Avro kernels (rh_espec_size / rh_espec_emit)
 };
 
 namespace {
@@ -243,20 +244,21 @@ uint64_t spec_min_records() {
 
 // Specialised kernels of this schema on `device`: code object from the kernel cache, or (allow_compile)
 // generated + compiled with hiprtc on the spot.  A failure is remembered (ok = false, why).
-const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile) {
+const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile, bool encode = false) {
   std::lock_guard<std::mutex> g(s->mu);
-  auto it = s->spec.find(device);
-  if (it != s->spec.end() && (it->second.ok || !allow_compile || it->second.why != "not cached")) return it->second;
+  std::map<int, SpecKernel>& table = encode ? s->espec : s->spec;
+  auto it = table.find(device);
+  if (it != table.end() && (it->second.ok || !allow_compile || it->second.why != "not cached")) return it->second;
   SpecKernel k;
   try {
-    std::vector<char> image = rh::get_kernel_image(*s->cs, allow_compile, nullptr);
+    std::vector<char> image = rh::get_kernel_image(*s->cs, allow_compile, nullptr, encode);
     if (image.empty()) {
       k.why = "not cached";
     } else {
       hipError_t e = hipModuleLoadData(&k.mod, image.data());
       if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
-      e = hipModuleGetFunction(&k.size_fn, k.mod, "rh_spec_size");
-      if (e == hipSuccess) e = hipModuleGetFunction(&k.emit_fn, k.mod, "rh_spec_emit");
+      e = hipModuleGetFunction(&k.size_fn, k.mod, encode ? "rh_espec_size" : "rh_spec_size");
+      if (e == hipSuccess) e = hipModuleGetFunction(&k.emit_fn, k.mod, encode ? "rh_espec_emit" : "rh_spec_emit");
       if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.size_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.emit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -266,8 +268,8 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile) {
   } catch (const std::exception& e) {
     k.why = e.what();
   }
-  s->spec[device] = k;
-  return s->spec[device];
+  table[device] = k;
+  return table[device];
 }
 
 int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream) {
@@ -741,30 +743,38 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   return res.release();
 }
 
-int to_host_impl(rh_device_result* r, ArrowArray* out_chunks) {
+// Device range -> freshly owned host memory.  Large results land in pooled PINNED memory (the copy then runs at PCIe
+// speed, 57 GB/s measured) as long as a cached block is free or the pinned memory lent to still-live results stays
+// under a bound; a caller that keeps many results alive gets pageable memory instead of a fresh 0.15 ms/MB
+// hipHostMalloc per call.
+Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device) {
   Slab* slab = new Slab();
   try {
-    // Large results land in pooled PINNED memory (the copy then runs at PCIe speed, 57 GB/s measured) as long as a
-    // cached block is free or the pinned memory lent to still-live results stays under a bound; a caller that keeps
-    // many results alive gets pageable memory instead of a fresh 0.15 ms/MB hipHostMalloc per call.
-    if (r->arena_bytes >= (1ull << 20)) {
-      slab->pinned = pin_pool().try_get(r->arena_bytes, r->device);
-      const uint64_t bound = std::max<uint64_t>(4ull << 30, 2 * r->arena_bytes);
-      if (!slab->pinned.p && Slab::pinned_result_bytes().load() + r->arena_bytes <= bound)
-        slab->pinned = pin_pool().get(r->arena_bytes, r->device);
+    if (bytes >= (1ull << 20)) {
+      slab->pinned = pin_pool().try_get(bytes, device);
+      const uint64_t bound = std::max<uint64_t>(4ull << 30, 2 * bytes);
+      if (!slab->pinned.p && Slab::pinned_result_bytes().load() + bytes <= bound)
+        slab->pinned = pin_pool().get(bytes, device);
       if (slab->pinned.p) {
         Slab::pinned_result_bytes().fetch_add(slab->pinned.size);
         slab->base = slab->pinned.p;
       }
     }
-    if (!slab->base && posix_memalign(&slab->base, 64, std::max<uint64_t>(r->arena_bytes, 64)) != 0) throw std::bad_alloc();
-    hipError_t e = hipMemcpy(slab->base, r->arena.ptr(), r->arena_bytes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e));
+    if (!slab->base && posix_memalign(&slab->base, 64, std::max<uint64_t>(bytes, 64)) != 0) throw std::bad_alloc();
+    if (bytes) {
+      hipError_t e = hipMemcpy(slab->base, dptr, bytes, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e));
+    }
   } catch (...) {
     slab->free_mem();
     delete slab;
     throw;
   }
+  return slab;
+}
+
+int to_host_impl(rh_device_result* r, ArrowArray* out_chunks) {
+  Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device);
   slab->refs.store(1);   // guard while building
   for (uint32_t c = 0; c < r->k; c++) export_chunk(*r, c, (const uint8_t*)slab->base, slab, &out_chunks[c]);
   if (slab->refs.fetch_sub(1) == 1) { slab->free_mem(); delete slab; }
@@ -875,6 +885,8 @@ void rh_schema_free(rh_schema* s) {
   }
   for (auto& kv : s->spec)
     if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+  for (auto& kv : s->espec)
+    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   delete s;
 }
 
@@ -906,13 +918,24 @@ char* rh_schema_kernel_source(const rh_schema* s) {
   }
 }
 
+char* rh_schema_encode_kernel_source(const rh_schema* s) {
+  if (!s) return nullptr;
+  try {
+    return dup_msg(rh::generate_encode_source(*s->cs));
+  } catch (...) {
+    return nullptr;
+  }
+}
+
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
   if (!s) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
-    bool hit = false;
+    bool hit = false, ehit = false;
     std::vector<char> image = rh::get_kernel_image(*s->cs, true, &hit);
     if (image.empty()) throw std::runtime_error("kernel image empty");
-    if (cached) *cached = hit ? 1 : 0;
+    image = rh::get_kernel_image(*s->cs, true, &ehit, true);       // and the Arrow -> Avro pair
+    if (image.empty()) throw std::runtime_error("encode kernel image empty");
+    if (cached) *cached = (hit && ehit) ? 1 : 0;
     return RH_OK;
   });
 }
@@ -1012,6 +1035,7 @@ struct EncodeBinder {
   const CompiledSchema& cs;
   std::vector<InBuf> in;
   std::vector<StrSrc> strs;   // by node id
+  uint64_t max_rows = 0;      // longest array bound (sizes the shared all-ones validity bitmap)
 
   explicit EncodeBinder(const CompiledSchema& c) : cs(c), in(c.bufs.size()), strs(c.nodes.size()) {}
 
@@ -1036,6 +1060,8 @@ struct EncodeBinder {
       if (const rh::AvroType* inner = null_inner(*t)) t = inner;     // 2-variant null union: the node is the inner type, nullable
     const DecNode& n = cs.nodes[id];
     const std::string fmt = fs->format ? fs->format : "";
+    if (len < 0 || off < 0) throw EncodeError("fast_encode: arrow array downcast failed");
+    max_rows = std::max<uint64_t>(max_rows, (uint64_t)len);
     switch (n.kind) {
       case rh::NK_NULL:
         return;
@@ -1147,19 +1173,15 @@ struct EncodeBinder {
   }
 };
 
-struct BinSlab {          // host memory of the produced BinaryArrays, shared by the k chunks
-  std::atomic<int> refs{0};
-  void* base = nullptr;
-};
-struct BinPriv {
+struct BinPriv {          // one produced BinaryArray; the k chunks share one host Slab
   const void* buffers[3];
-  BinSlab* slab;
+  Slab* slab;
 };
 void release_binary(ArrowArray* a) {
   if (!a || !a->release) return;
   BinPriv* p = (BinPriv*)a->private_data;
   if (p->slab->refs.fetch_sub(1) == 1) {
-    std::free(p->slab->base);
+    p->slab->free_mem();
     delete p->slab;
   }
   delete p;
@@ -1179,7 +1201,8 @@ std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, 
     if (s.offsets && s.data) sym.assign((const char*)s.data + s.offsets[e.detail], (size_t)(s.offsets[e.detail + 1] - s.offsets[e.detail]));
     return "fast_encode: enum symbol '" + sym + "' not in schema";
   }
-  return "encode error";
+  std::snprintf(buf, sizeof buf, "encode error (code %u, op %u, detail %lld)", e.code, e.pad, (long long)e.detail);
+  return buf;
 }
 
 int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschema, uint64_t num_chunks, const rh_opts* opts,
@@ -1208,18 +1231,27 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   const int nbuf = (int)cs.bufs.size();
   const DeviceProgram& dp = device_program(s, device);
 
-  // ---- inputs -> HBM (every buffer rebased to logical row 0)
+  // ---- inputs -> HBM.  Every buffer is rebased to logical row 0 and padded so that the kernels' unconditional
+  // loads (encode_walk.h: row cursors up to one past the last row, 32-byte string reads) stay inside the arena; a validity bitmap the batch does
+  // not carry (no nulls) is the shared all-ones bitmap at the end.
   std::vector<uint64_t> ioff((size_t)nbuf, 0);
   uint64_t itot = 0;
   for (int b = 0; b < nbuf; b++) {
     ioff[b] = itot;
-    itot += align_up(binder.in[b].bytes + 8, kAlign);
+    itot += align_up(binder.in[b].bytes + 64, kAlign);
   }
-  Lease din(dev_pool(), std::max<uint64_t>(itot, kAlign), device);
+  const uint64_t o_ones = itot;
+  const uint64_t ones_bytes = align_up(binder.max_rows / 8 + 16, kAlign);
+  itot += ones_bytes;
+  Lease din(dev_pool(), itot, device);
   Timer th;
-  for (int b = 0; b < nbuf; b++)
+  HIPCHK(hipMemsetAsync(din.ptr() + o_ones, 0xFF, ones_bytes, stream));
+  for (int b = 0; b < nbuf; b++) {
     if (binder.in[b].host && binder.in[b].bytes)
       HIPCHK(hipMemcpyAsync(din.ptr() + ioff[b], binder.in[b].host, binder.in[b].bytes, hipMemcpyHostToDevice, stream));
+    else     // an empty column: zero offsets keep the kernels' unconditional second-level loads inside the arena
+      HIPCHK(hipMemsetAsync(din.ptr() + ioff[b], 0, kAlign, stream));
+  }
 
   // ---- workspace: [first_bad][totals u64 k] | errinfo | blocksum | blockbase | in_ptr | in_bitoff | outptr
   const uint64_t o_tot = 16;
@@ -1229,7 +1261,8 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   const uint64_t o_bbase = align_up(o_bsum + 4ull * nblocks, kAlign);
   const uint64_t o_tab = align_up(o_bbase + 4ull * nblocks, kAlign);
   const uint64_t tab_bytes = align_up(12ull * std::max(nbuf, 1) + 16ull * k, kAlign);
-  const uint64_t ws_bytes = o_tab + tab_bytes;
+  const uint64_t o_rlen = o_tab + tab_bytes;
+  const uint64_t ws_bytes = o_rlen + align_up(4ull * rh::kBlock * std::max<uint64_t>(nblocks, 1), kAlign);
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
   Lease htab(pin_pool(), tab_bytes, device);
@@ -1239,8 +1272,10 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   void** h_out = (void**)(htab.ptr() + 12ull * std::max(nbuf, 1) + ((12ull * std::max(nbuf, 1)) % 8 ? 4 : 0));
   const uint64_t o_out = (uint64_t)((uint8_t*)h_out - htab.ptr());
   for (int b = 0; b < nbuf; b++) {
-    h_inptr[b] = binder.in[b].host && binder.in[b].bytes ? (uint64_t)(uintptr_t)(din.ptr() + ioff[b]) : 0;
-    h_bitoff[b] = binder.in[b].bitoff;
+    const bool have = binder.in[b].host && binder.in[b].bytes;
+    const bool bitmap = cs.bufs[b].kind == rh::BK_BITMAP;
+    h_inptr[b] = (uint64_t)(uintptr_t)(din.ptr() + (have || !bitmap ? ioff[b] : o_ones));
+    h_bitoff[b] = have ? binder.in[b].bitoff : 0;
   }
 
   rh::EParams E;
@@ -1255,16 +1290,33 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   E.blockbase = (const uint32_t*)(ws.ptr() + o_bbase);
   E.first_bad = (unsigned long long*)ws.ptr();
   E.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
+  E.rowlen = (uint32_t*)(ws.ptr() + o_rlen);
   // the scan kernel of the decode side, one counter
   rh::KParams SP;
   std::memset(&SP, 0, sizeof SP);
   SP.K = 1; SP.k = k; SP.bpc = (uint32_t)bpc64; SP.nblocks = nblocks;
   SP.blocksum = E.blocksum; SP.blockbase = (uint32_t*)(ws.ptr() + o_bbase); SP.totals = (uint64_t*)(ws.ptr() + o_tot);
 
-  const uint32_t lds = rh_enc_lds_bytes(cs.ndom, cs.list_depth);
-  auto check_bad = [&](const uint8_t* h) {
+  // kernel form: schema-specialised (hiprtc, cached per schema) or the generic interpreter, like the decode side
+  const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
+  const SpecKernel* sk = nullptr;
+  if (mode != RH_KERNEL_GENERIC && n > 0) {
+    const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
+    const SpecKernel& k0 = spec_kernel(s, device, may_compile, true);
+    if (k0.ok) sk = &k0;
+    else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised encode kernel unavailable: " + k0.why);
+  }
+  const uint32_t lds = sk ? 32u : rh_enc_lds_bytes(cs.ndom, cs.list_depth);   // encode_walk.h: enc_lds_fixed_bytes
+  auto launch = [&](bool emit, uint32_t lds_bytes) -> int {
+    if (!sk) return emit ? rh_launch_eemit(&E, lds_bytes, stream) : rh_launch_esize(&E, lds_bytes, stream);
+    rh::EParams copy = E;
+    void* args[] = {&copy};
+    return (int)hipModuleLaunchKernel(emit ? sk->emit_fn : sk->size_fn, nblocks, 1, 1, rh::kBlock, 1, 1, lds_bytes, stream, args, nullptr);
+  };
+  auto check_bad = [&](const uint8_t* h, const char* pass) {
     unsigned long long fb = *(const unsigned long long*)h;
     if (!fb) return;
+    if (std::getenv("RUHVRO_HIP_DEBUG")) std::fprintf(stderr, "rh_encode: %s pass reports first_bad=%llx\n", pass, fb);
     const uint64_t rec = ~fb;
     uint64_t c = sz ? std::min<uint64_t>(rec / sz, k - 1) : 0;
     uint64_t bl = c * bpc64 + (rec - c * sz) / rh::kBlock;
@@ -1280,13 +1332,13 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   ev.rec(0, stream);
   std::vector<uint64_t> totals((size_t)k, 0);
   if (n > 0) {
-    if (rh_launch_esize(&E, lds, stream)) throw HipError("e_size launch failed");
+    if (launch(false, lds)) throw HipError("e_size launch failed");
     ev.rec(1, stream);
     if (rh_launch_scan(&SP, stream)) throw HipError("k_scan launch failed");
     ev.rec(2, stream);
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    check_bad(hctrl.ptr());
+    check_bad(hctrl.ptr(), "size");
     std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * k);
   } else {
     HIPCHK(hipStreamSynchronize(stream));
@@ -1315,19 +1367,23 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   }
   HIPCHK(hipMemcpyAsync(ws.ptr() + o_tab + o_out, (uint8_t*)h_out, 16ull * k, hipMemcpyHostToDevice, stream));
   if (n == 0) HIPCHK(hipMemsetAsync(dout.ptr(), 0, 4, stream));   // offsets[0] of the single empty chunk
+  // staging window of rh_e_emit: the mean workgroup's bytes + 15 % + 2 KB, within the 64 KB a launch gets by default
+  uint64_t sum = 0;
+  for (auto t : totals) sum += t;
+  uint64_t win = nblocks ? sum / nblocks : 0;
+  win = align_up(win + win * 15 / 100 + 2048, 16);
+  win = std::min<uint64_t>(win, (65536 - lds) & ~15ull);
+  E.win_bytes = (uint32_t)win;
   ev.rec(3, stream);
-  if (n > 0 && rh_launch_eemit(&E, lds, stream)) throw HipError("e_emit launch failed");
+  if (n > 0 && launch(true, lds + E.win_bytes)) throw HipError("e_emit launch failed");
   ev.rec(4, stream);
   HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), 16, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
-  check_bad(hctrl.ptr());
+  check_bad(hctrl.ptr(), "emit");
 
   // ---- results -> host, one slab shared by the k BinaryArrays
   Timer td;
-  BinSlab* slab = new BinSlab();
-  if (posix_memalign(&slab->base, 64, std::max<uint64_t>(otot, 64)) != 0) { delete slab; throw std::bad_alloc(); }
-  hipError_t ce = hipMemcpy(slab->base, dout.ptr(), std::max<uint64_t>(otot, 4), hipMemcpyDeviceToHost);
-  if (ce != hipSuccess) { std::free(slab->base); delete slab; throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(ce)); }
+  Slab* slab = slab_from_device(dout.ptr(), std::max<uint64_t>(otot, 4), device);
   slab->refs.store((int)k);
   for (uint32_t c = 0; c < k; c++) {
     const uint64_t rows = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
@@ -1355,6 +1411,8 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
     stats->emit_kernel_ms = ev.ms(3, 4);
     stats->d2h_ms = td.ms();
     stats->total_ms = total.ms();
+    stats->specialized = sk ? 1 : 0;
+    stats->lds_bytes = lds + E.win_bytes;
   }
   return RH_OK;
 }

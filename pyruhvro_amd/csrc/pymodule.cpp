@@ -166,7 +166,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
 }
 
 
-// encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False)
+// encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)
 //   array_addr / schema_addr: ArrowArray / ArrowSchema structs the caller exported the batch's struct array into
 //   (they are released here).  -> (list[int] addresses of malloc'd ArrowArray structs ("z" arrays), stats | None)
 // src/lib.rs:91-106: serialize_record_batch, the GIL is released around the work like py.detach there.
@@ -176,7 +176,8 @@ PyObject* py_encode(PyObject*, PyObject* args) {
   int device = -1;
   unsigned long long stream = 0;
   int want_stats = 0;
-  if (!PyArg_ParseTuple(args, "OKKK|iKp", &cap, &a_addr, &s_addr, &num_chunks, &device, &stream, &want_stats)) return nullptr;
+  int kernel = RH_KERNEL_AUTO;
+  if (!PyArg_ParseTuple(args, "OKKK|iKpi", &cap, &a_addr, &s_addr, &num_chunks, &device, &stream, &want_stats, &kernel)) return nullptr;
   ArrowArray* arr = (ArrowArray*)(uintptr_t)a_addr;
   ArrowSchema* sch = (ArrowSchema*)(uintptr_t)s_addr;
   auto drop_inputs = [&] {
@@ -193,7 +194,7 @@ PyObject* py_encode(PyObject*, PyObject* args) {
   ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
   rh_opts opts;
   opts.device = device;
-  opts.flags = 0;
+  opts.flags = kernel;
   opts.stream = (void*)(uintptr_t)stream;
   rh_stats st;
   std::memset(&st, 0, sizeof st);
@@ -242,7 +243,7 @@ PyMethodDef methods[] = {
     {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
     {"export_schema", py_export_schema, METH_VARARGS, "export_schema(capsule) -> address of ArrowSchema"},
     {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
-    {"encode", py_encode, METH_VARARGS, "encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False)"},
+    {"encode", py_encode, METH_VARARGS, "encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
     {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},

@@ -11,14 +11,17 @@ namespace rh {
 int spec_tile_records();
 // HIP source of the specialised k_size / k_emit pair for this schema.
 std::string generate_kernel_source(const CompiledSchema& cs);
+// HIP source of the specialised Arrow -> Avro pair (rh_espec_size / rh_espec_emit) for this schema.
+std::string generate_encode_source(const CompiledSchema& cs);
 // Content hash of (source + the device headers it includes): the on-disk cache key.
-std::string kernel_cache_key(const std::string& source);
+std::string kernel_cache_key(const std::string& source, bool encode = false);
 // Directory of cached code objects: $RUHVRO_HIP_KERNEL_CACHE or <library dir>/_kcache.
 std::string kernel_cache_dir();
 // hiprtc: source -> gfx950 code object (works without a GPU).  Throws std::runtime_error.
 std::vector<char> compile_kernel(const std::string& source, std::string& log);
 // Cached code object, compiling (and storing) on a miss when allowed; empty if absent and !allow_compile.
-std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache);
+// `encode` selects the Arrow -> Avro kernels instead of the decode kernels.
+std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache, bool encode = false);
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
 inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw) {

@@ -60,6 +60,9 @@ def known_schemas() -> List[str]:
         for c in cases.differential_cases():
             out.append(c[1])
         out.append(cases.logical_case()[0])
+        out += cases.encode_extra_schemas()
+        import random_cases
+        out += [random_cases.random_schema(seed) for seed in range(random_cases.PREBUILT_SEEDS)]
         g = json.load(open(os.path.join(root, "tests", "golden", "reference_vectors.json")))
         out += [json.dumps(s) for s in g["schemas"].values()]
     except Exception:  # tests/ not present (installed package): benchmark schemas only

@@ -245,3 +245,19 @@ def nesting_cases():
         vals.append({"o": o})
     out.append(("deep_nullfill", s, _enc(s, vals)))
     return out
+
+
+# schemas that only the Arrow -> Avro GPU tests use (tests/test_gpu_encode.py); listed here so that
+# pyruhvro_amd.prebuild.known_schemas() compiles their specialised kernels ahead of the GPU run
+ENC_WINDOW_SCHEMA = json.dumps({"type": "record", "name": "r", "fields": [
+    {"name": "id", "type": "long"}, {"name": "t", "type": "string"}, {"name": "o", "type": ["null", "string"]},
+    {"name": "xs", "type": {"type": "array", "items": "string"}}]})
+ENC_VALIDITY_SCHEMA = json.dumps({"type": "record", "name": "r", "fields": [
+    {"name": "a", "type": "long"}, {"name": "b", "type": ["null", "string"]}]})
+ENC_LONG_ENUM_SCHEMA = json.dumps({"type": "record", "name": "r", "fields": [
+    {"name": "e", "type": {"type": "enum", "name": "E", "symbols": ["SHORT", "A_SYMBOL_LONGER_THAN_SIXTEEN_BYTES", "MID_LENGTH_SYM16"]}},
+    {"name": "f", "type": ["null", {"type": "enum", "name": "F", "symbols": ["x", "yy", "zzz", "wwww", "vvvvv"]}]}]})
+
+
+def encode_extra_schemas():
+    return [ENC_WINDOW_SCHEMA, ENC_VALIDITY_SCHEMA, ENC_LONG_ENUM_SCHEMA]

@@ -17,6 +17,9 @@ PRIMS = ["int", "long", "float", "double", "boolean", "string",
          {"type": "long", "logicalType": "timestamp-micros"}]
 
 
+PREBUILT_SEEDS = 40      # seeds whose specialised kernels build() compiles ahead of the GPU run (prebuild.known_schemas)
+
+
 def _rand_type(r: random.Random, depth: int, counter: List[int]):
     def named(kind):
         counter[0] += 1

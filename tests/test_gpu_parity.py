@@ -118,8 +118,7 @@ def test_generated_records(name, n, k):
 def test_random_schemas_and_records(seed, kernel):
     """Seeded random schemas inside the direct-decode subset x random records (tests/random_cases.py)."""
     import random_cases
-    if kernel == cabi.KERNEL_SPECIALIZED and seed >= 6:
-        pytest.skip("specialised kernels: 6 random schemas (each is a run-time hiprtc compile)")
+    assert seed < random_cases.PREBUILT_SEEDS      # build() compiled these schemas' specialised kernels ahead of time
     js, recs = random_cases.random_case(seed, 700)
     _check(recs, js, 1 + seed % 4)
 

@@ -25,12 +25,30 @@ def test_prebuild_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
     schema = SCHEMAS["t_enum"]
     assert cabi.prebuild(schema) is False            # compiled now
     files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
-    assert len(files) == 1
-    blob = open(os.path.join(tmp_path, files[0]), "rb").read()
-    assert blob[:4] == b"\x7fELF" and b"rh_spec_emit" in blob and b"gfx950" in blob
+    assert len(files) == 2                           # the decode pair and the Arrow -> Avro pair
+    blobs = [open(os.path.join(tmp_path, f), "rb").read() for f in files]
+    assert all(b[:4] == b"\x7fELF" and b"gfx950" in b for b in blobs)
+    assert sum(b"rh_spec_emit" in b for b in blobs) == 1 and sum(b"rh_espec_emit" in b for b in blobs) == 1
     assert cabi.prebuild(schema) is True             # cache hit
-    assert cabi.prebuild(SCHEMAS["t_union"]) is False   # different schema -> different key
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
+    assert cabi.prebuild(SCHEMAS["t_union"]) is False   # different schema -> different keys
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 4
+
+
+def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
+    """The specialised Arrow -> Avro walk is the schema program unrolled over encode_walk.h's handlers with the
+    e_*_load half of every field of a row domain hoisted in front of the first e_*_put (latency-bound walk)."""
+    src = cabi.encode_kernel_source(SCHEMAS["full"])
+    body = src[src.index("static __device__ __forceinline__ void walk"):]
+    first_put = body.index("_put<MODE>")
+    dom0_loads = [ln for ln in body[:first_put].splitlines() if "_load(c, op" in ln]
+    assert len(dom0_loads) >= 15                     # every dom-0 field of the generate_avro.py schema
+    assert "rh_espec_size" in src and "rh_espec_emit" in src
+    loop = body[body.index("for (;;) {"):]
+    assert loop.index("e_list_next") < loop.index("e_span_load") < loop.index("e_string_put")   # list items: loads per iteration
+    # enum symbols are folded into the kernel as (length, masked dword) compares
+    assert "n == 1u && (a.x & 0x000000ffu) == 0x00000041u" in src
+    with pytest.raises(ValueError):
+        cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":"bytes"}]}')
 
 
 def test_unsupported_schema_has_no_kernel():
