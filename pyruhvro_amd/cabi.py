@@ -201,6 +201,29 @@ def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_c
     return (out, st.as_dict()) if want_stats else out
 
 
+def decode_slices(ptrs: np.ndarray, lens: np.ndarray, schema_json: str, num_chunks: int,
+                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO):
+    """rh_decode: one (pointer, length) pair per record, the form the CPython boundary extracts from list[bytes]
+    (u64 addresses / u64 lengths; the caller keeps the pointed-to memory alive) -> list[RecordBatch]."""
+    L = lib()
+    s = Schema.get(schema_json)
+    ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    n = len(ptrs)
+    k = L.rh_clamp_chunks(n, num_chunks)
+    arr = (ArrowArray * k)()
+    out_k = C.c_uint32()
+    st = RhStats()
+    err = C.c_char_p()
+    opts = RhOpts(device, kernel, None)
+    rc = L.rh_decode(s.handle, ptrs.ctypes.data, lens.ctypes.data, n, num_chunks, C.byref(opts), arr,
+                     C.byref(out_k), C.byref(st), C.byref(err))
+    if rc != RH_OK:
+        _raise(rc, err)
+    out = _import_chunks(arr, out_k.value, s.arrow_schema)
+    return (out, st.as_dict()) if want_stats else out
+
+
 class DeviceResult:
     """Owns an rh_device_result (Arrow buffers resident in HBM)."""
 

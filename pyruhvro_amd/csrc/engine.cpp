@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -505,24 +506,33 @@ struct Events {
   float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
 };
 
+// Chunk geometry of a call that decodes a contiguous RANGE of another call's chunks (the pipelined host path):
+// k chunks of sz rows, the last one rows_last, instead of the split derived from (n, num_chunks).
+struct ChunkGeo {
+  uint64_t sz, rows_last;
+  uint32_t k;
+  uint64_t payload_bytes;   // bytes of the range's records (data_len is the absolute end offset there)
+};
+
 rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
-                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats);
+                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo);
 
 rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
-                                     uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats) {
+                                     uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats,
+                                     const ChunkGeo* geo = nullptr) {
   try {
-    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats);
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats, geo);
   } catch (const NeedWideIndex&) {
     rh_opts o;
     if (opts) o = *opts;
     else { o.device = -1; o.stream = nullptr; }
     o.flags = RH_KERNEL_GENERIC;
-    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats);
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats, geo);
   }
 }
 
 rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
-                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats) {
+                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo) {
   const CompiledSchema& cs = *s->cs;
   int device = 0;
   if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
@@ -538,10 +548,10 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   r.cs = &cs;
   r.device = device;
   r.n = n;
-  const uint32_t k = rh_clamp_chunks(n, num_chunks);
+  const uint32_t k = geo ? geo->k : rh_clamp_chunks(n, num_chunks);
   r.k = k;
-  r.sz = n / k;
-  r.rows_last = n - (uint64_t)(k - 1) * r.sz;
+  r.sz = geo ? geo->sz : n / k;
+  r.rows_last = geo ? geo->rows_last : n - (uint64_t)(k - 1) * r.sz;
   const int K = cs.K, nnodes = (int)cs.nodes.size(), nbuf = (int)cs.bufs.size();
   const DeviceProgram& dp = device_program(s, device);
 
@@ -596,7 +606,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)
   const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
-  const uint64_t avg = n ? data_len / n + 1 : 16;
+  const uint64_t payload = geo ? geo->payload_bytes : data_len;
+  const uint64_t avg = n ? payload / n + 1 : 16;
   uint64_t win = align_up(avg * tile * 115 / 100 + 2048 * tile / rh::kBlock, 16);
   win = std::max<uint64_t>(win, 8192 * tile / rh::kBlock);
   const uint64_t lds_cap = 160 * 1024 - 512;
@@ -730,7 +741,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   }
   if (stats) {
     stats->records = n;
-    stats->input_bytes = data_len;
+    stats->input_bytes = payload;
     stats->output_bytes = exact;
     stats->chunks = k;
     stats->blocks = nblocks;
@@ -747,7 +758,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 // speed, 57 GB/s measured) as long as a cached block is free or the pinned memory lent to still-live results stays
 // under a bound; a caller that keeps many results alive gets pageable memory instead of a fresh 0.15 ms/MB
 // hipHostMalloc per call.
-Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device) {
+Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStream_t stream = nullptr) {
   Slab* slab = new Slab();
   try {
     if (bytes >= (1ull << 20)) {
@@ -762,7 +773,8 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device) {
     }
     if (!slab->base && posix_memalign(&slab->base, 64, std::max<uint64_t>(bytes, 64)) != 0) throw std::bad_alloc();
     if (bytes) {
-      hipError_t e = hipMemcpy(slab->base, dptr, bytes, hipMemcpyDeviceToHost);
+      hipError_t e = hipMemcpyAsync(slab->base, dptr, bytes, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
       if (e != hipSuccess) throw HipError(std::string("D2H copy failed: ") + hipGetErrorString(e));
     }
   } catch (...) {
@@ -773,8 +785,8 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device) {
   return slab;
 }
 
-int to_host_impl(rh_device_result* r, ArrowArray* out_chunks) {
-  Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device);
+int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream = nullptr) {
+  Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
   slab->refs.store(1);   // guard while building
   for (uint32_t c = 0; c < r->k; c++) export_chunk(*r, c, (const uint8_t*)slab->base, slab, &out_chunks[c]);
   if (slab->refs.fetch_sub(1) == 1) { slab->free_mem(); delete slab; }
@@ -810,31 +822,163 @@ void require_device() {
     throw HipError("no HIP device available: the ruhvro_hip engine has no CPU decode path");
 }
 
+// Lets the groups of a pipelined call through one PCIe direction in group order, one at a time: group g+1's H2D then
+// runs while group g's kernels and D2H do, and the two directions of the link stay busy together.
+struct Turnstile {
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t next = 0;
+  void enter(uint32_t ticket) {
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] { return next == ticket; });
+  }
+  void leave() {
+    { std::lock_guard<std::mutex> l(mu); next++; }
+    cv.notify_all();
+  }
+  void finish(uint32_t ticket) {      // a group that never reached this gate (it failed earlier) must not hold up its successors
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] { return next >= ticket; });
+    if (next == ticket) {
+      next++;
+      l.unlock();
+      cv.notify_all();
+    }
+  }
+};
+struct TurnstilePass {      // RAII: a group that fails still lets the next one in
+  Turnstile* t;
+  bool in = false;
+  TurnstilePass(Turnstile* ts, uint32_t ticket) : t(ts) { if (t) { t->enter(ticket); in = true; } }
+  void done() { if (t && in) { t->leave(); in = false; } }
+  ~TurnstilePass() { done(); }
+};
+
+// rows [0, n) of `offsets` (absolute byte offsets into `data`): H2D, the kernels, D2H -- all on `stream`.
+void decode_packed_range(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
+                         const ChunkGeo* geo, const rh_opts* opts, int device, hipStream_t stream, ArrowArray* out_chunks,
+                         uint32_t* out_k, rh_stats* stats, Turnstile* h2d_gate, Turnstile* d2h_gate, uint32_t ticket) {
+  const uint64_t lo = offsets[0], hi = offsets[n];
+  // the kernels index the payload with the absolute offsets: hand them a (virtual) base such that base + lo is where
+  // the range's first byte lands, congruent to lo modulo 16 so that the 16-byte window rows stay aligned
+  const uint64_t lead = 16 + (lo & 15);
+  const uint64_t o_off = align_up(lead + (hi - lo) + 32, kAlign);
+  Lease din(dev_pool(), o_off + 8 * (n + 1), device);
+  rh_opts o;
+  o.device = device;
+  o.flags = opts ? opts->flags : 0;
+  o.stream = (void*)stream;
+  float h2d = 0.f;
+  {
+    TurnstilePass pass(h2d_gate, ticket);
+    Timer th;
+    if (hi > lo) HIPCHK(hipMemcpyAsync(din.ptr() + lead, data + lo, hi - lo, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    h2d = th.ms();
+  }
+  const uint8_t* base = din.ptr() + lead - lo;
+  std::unique_ptr<rh_device_result> r(decode_device_impl(s, base, (const uint64_t*)(din.ptr() + o_off), hi, n, num_chunks,
+                                                         &o, stats, geo));
+  float d2h = 0.f;
+  {
+    TurnstilePass pass(d2h_gate, ticket);
+    Timer td;
+    to_host_impl(r.get(), out_chunks, stream);
+    d2h = td.ms();
+  }
+  if (out_k) *out_k = r->k;
+  if (stats) {
+    stats->h2d_ms = h2d;
+    stats->d2h_ms = d2h;
+  }
+}
+
+// Payload bytes from which a call is pipelined.  Measured on MI355X (profiles/r01h_pipeline_e2e.jsonl, 10M records,
+// 1.2 GB in / 1.7 GB out): with the records in PINNED memory (rh_decode packs them there) the two PCIe directions
+// overlap and H2D + kernels + D2H drop from 55 to 43 ms; from PAGEABLE memory (rh_decode_packed) the runtime's staged
+// H2D copies do not overlap with the D2H copies of other streams (56.5 vs 55.0 ms), and at 1M records the extra
+// streams / launches cost more than the overlap gains (7.1 vs 5.7 ms).  So: pinned source and >= 256 MB by default;
+// RUHVRO_HIP_PIPELINE_MIN_MB overrides the threshold for both sources (tests force 0).
+uint64_t pipeline_min_bytes(bool source_pinned) {      // read per call: tests switch it
+  if (const char* e = std::getenv("RUHVRO_HIP_PIPELINE_MIN_MB")) return (uint64_t)std::strtoull(e, nullptr, 10) << 20;
+  return source_pinned ? (256ull << 20) : ~0ull;
+}
+
 int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
-                       const rh_opts* opts, ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, float pack_ms) {
+                       const rh_opts* opts, ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, float pack_ms,
+                       bool source_pinned) {
   require_device();
   Timer total;
   int device = 0;
   if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
   else HIPCHK(hipGetDevice(&device));
-  hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
-  const uint64_t data_len = offsets[n];
-  const uint64_t o_off = align_up(data_len + 16, kAlign);
-  Lease din(dev_pool(), o_off + 8 * (n + 1), device);
-  Timer th;
-  if (data_len) HIPCHK(hipMemcpyAsync(din.ptr(), data, data_len, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));
-  const float h2d = th.ms();
-  std::unique_ptr<rh_device_result> r(decode_device_impl(s, din.ptr(), (const uint64_t*)(din.ptr() + o_off), data_len,
-                                                         n, num_chunks, opts, stats));
-  Timer td;
-  to_host_impl(r.get(), out_chunks);
-  if (out_k) *out_k = r->k;
+  hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
+  const uint32_t k = rh_clamp_chunks(n, num_chunks);
+  const uint64_t bytes = n ? offsets[n] - offsets[0] : 0;
+
+  // Large calls on the default stream are pipelined: chunks are independent (deserialize.rs:92-120), so contiguous
+  // groups of chunks go through H2D -> kernels -> D2H on their own streams, staggered so that the link carries one
+  // group's results out while the next group's records come in.
+  const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned)) ? std::min<uint32_t>(k, 8) : 1;
+  if (groups <= 1) {
+    decode_packed_range(s, data, offsets, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats,
+                        nullptr, nullptr, 0);
+    if (stats) {
+      stats->pack_ms = pack_ms;
+      stats->total_ms = total.ms() + pack_ms;
+    }
+    return RH_OK;
+  }
+
+  const uint64_t sz = n / k, rows_last = n - (uint64_t)(k - 1) * sz;
+  std::vector<rh_stats> gstats(groups);
+  std::vector<std::exception_ptr> failed(groups);
+  Turnstile h2d_gate, d2h_gate;
+  std::vector<std::thread> th;
+  for (uint32_t g = 0; g < groups; g++) {
+    th.emplace_back([&, g] {
+      hipStream_t st = nullptr;
+      try {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        const uint32_t c0 = (uint32_t)((uint64_t)k * g / groups), c1 = (uint32_t)((uint64_t)k * (g + 1) / groups);
+        const uint64_t r0 = (uint64_t)c0 * sz, r1 = c1 == k ? n : (uint64_t)c1 * sz;
+        ChunkGeo geo;
+        geo.k = c1 - c0;
+        geo.sz = sz;
+        geo.rows_last = c1 == k ? rows_last : sz;
+        geo.payload_bytes = offsets[r1] - offsets[r0];
+        std::memset(&gstats[g], 0, sizeof(rh_stats));
+        decode_packed_range(s, data, offsets + r0, r1 - r0, 0, &geo, opts, device, st, out_chunks + c0, nullptr,
+                            stats ? &gstats[g] : nullptr, &h2d_gate, &d2h_gate, g);
+      } catch (...) {
+        failed[g] = std::current_exception();
+      }
+      h2d_gate.finish(g);
+      d2h_gate.finish(g);
+      if (st) (void)hipStreamDestroy(st);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (uint32_t g = 0; g < groups; g++) {
+    if (!failed[g]) continue;
+    for (uint32_t c = 0; c < k; c++)        // the call fails as a whole: drop what the other groups produced
+      if (out_chunks[c].release) out_chunks[c].release(&out_chunks[c]);
+    std::rethrow_exception(failed[g]);      // lowest group = lowest rows: the error the serial order meets first
+  }
+  if (out_k) *out_k = k;
   if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    for (const rh_stats& gs : gstats) {     // stage times are sums over the groups (they overlap in wall time)
+      stats->records += gs.records; stats->input_bytes += gs.input_bytes; stats->output_bytes += gs.output_bytes;
+      stats->blocks += gs.blocks;
+      stats->h2d_ms += gs.h2d_ms; stats->size_kernel_ms += gs.size_kernel_ms; stats->scan_kernel_ms += gs.scan_kernel_ms;
+      stats->emit_kernel_ms += gs.emit_kernel_ms; stats->d2h_ms += gs.d2h_ms;
+      stats->specialized = gs.specialized; stats->lds_bytes = gs.lds_bytes;
+    }
+    stats->chunks = k;
     stats->pack_ms = pack_ms;
-    stats->h2d_ms = h2d;
-    stats->d2h_ms = td.ms();
     stats->total_ms = total.ms() + pack_ms;
   }
   return RH_OK;
@@ -965,7 +1109,7 @@ int rh_decode_packed(const rh_schema* s, const uint8_t* data, const uint64_t* of
                      const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !offsets || !out_chunks) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
-    return decode_packed_impl(const_cast<rh_schema*>(s), data, offsets, n, num_chunks, opts, out_chunks, out_k, stats, 0.f);
+    return decode_packed_impl(const_cast<rh_schema*>(s), data, offsets, n, num_chunks, opts, out_chunks, out_k, stats, 0.f, false);
   });
 }
 
@@ -996,7 +1140,7 @@ int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* le
     }
     const float pack_ms = tp.ms();
     return decode_packed_impl(const_cast<rh_schema*>(s), dst, offsets.data(), n, num_chunks, opts, out_chunks, out_k,
-                              stats, pack_ms);
+                              stats, pack_ms, true);
   });
 }
 

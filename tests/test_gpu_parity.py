@@ -203,6 +203,40 @@ def test_chunk_semantics():
     assert P.deserialize_array_threaded_spawn(recs, SCHEMAS["full"], 3)[1].equals(P.deserialize_array_threaded(recs, SCHEMAS["full"], 3)[1])
 
 
+@pytest.fixture
+def pipelined(monkeypatch):
+    """Force the pipelined host path (groups of chunks on their own streams, engine.cpp decode_packed_impl) on small
+    inputs; by default it starts at 64 MB per call (the 1M / 10M config tests below run it at its default)."""
+    monkeypatch.setenv("RUHVRO_HIP_PIPELINE_MIN_MB", "0")
+
+
+def test_pipelined_host_path_is_identical_to_the_serial_one(pipelined):
+    for name, n, k in (("full", 103, 10), ("full", 5003, 7), ("cfg3", 1000, 8), ("array_and_map", 777, 3), ("full", 2, 2),
+                       ("flat4", 40000, 16), ("full", 1200, 500)):
+        out = _check(synth.records(name, n, seed=2), SCHEMAS[name], k)
+        kk = min(max(k, 1), n)
+        assert [b.num_rows for b in out] == [n // kk] * (kk - 1) + [n - (kk - 1) * (n // kk)]      # deserialize.rs:53-68
+    recs = synth.records("full", 3000, seed=4)
+    out, st = P.deserialize_array_threaded_with_stats(recs, SCHEMAS["full"], 16)
+    assert st["chunks"] == 16 and st["records"] == 3000 and st["emit_kernel_ms"] > 0 and st["d2h_ms"] > 0
+    data, offsets = c_walker.pack(recs)
+    for x, y in zip(out, cabi.decode_packed(data, offsets, SCHEMAS["full"], 16)):
+        assert_batches_identical(x, y)
+
+
+@pytest.mark.parametrize("case", cases.error_cases()[:8], ids=lambda c: c[0])
+def test_pipelined_errors_report_the_lowest_failing_group(pipelined, case):
+    _, schema, good, bad, msg = case
+    recs = good * 200 + [bad] + good * 100 + [b"\x80" * 11]
+    for k in (5, 9):
+        with pytest.raises(ValueError) as ei:
+            P.deserialize_array_threaded(recs, schema, k)
+        assert str(ei.value) == msg
+    # and the engine is healthy afterwards (no group left waiting at a gate)
+    ok = good * 50
+    _check(ok, schema, 4)
+
+
 def test_input_forms(kernel):
     recs = synth.records("cfg3", 300)
     a = P.deserialize_array_threaded(recs, SCHEMAS["cfg3"], 2)
