@@ -20,8 +20,26 @@ def _one(schema_json: str) -> Tuple[bool, str]:
         return False, str(e)
 
 
+def _cache_dir() -> str:
+    return os.environ.get("RUHVRO_HIP_KERNEL_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache")
+
+
+def _marker(schemas: List[str]) -> str:
+    import hashlib
+    h = hashlib.sha1("\0".join(sorted(schemas)).encode()).hexdigest()[:16]
+    return os.path.join(_cache_dir(), f"warm_{h}.ok")
+
+
+def cache_looks_warm(schemas: Iterable[str]) -> bool:
+    """True when a prebuild_many() of exactly these schemas completed against the current library build (it leaves a
+    marker next to the code objects; rebuilding the library prunes both).  Needs no compile and no child process."""
+    return os.path.exists(_marker(list(dict.fromkeys(schemas))))
+
+
 def prebuild_many(schemas: Iterable[str], jobs: int = 0, verbose: bool = False) -> List[str]:
-    """Compile every schema's kernels (parallel processes).  Returns the list of error messages."""
+    """Compile every schema's kernels (parallel processes).  Returns the list of error messages.
+    Forks workers: call it from a process that has not initialised the HIP runtime (build(), `python -m
+    pyruhvro_amd.prebuild`)."""
     uniq = list(dict.fromkeys(schemas))
     jobs = jobs or min(len(uniq), os.cpu_count() or 1, 16)
     errors: List[str] = []
@@ -36,6 +54,12 @@ def prebuild_many(schemas: Iterable[str], jobs: int = 0, verbose: bool = False) 
     for (hit, err), s in zip(results, uniq):
         if err:
             errors.append(err)
+    if not errors:
+        try:
+            os.makedirs(_cache_dir(), exist_ok=True)
+            open(_marker(uniq), "w").close()
+        except OSError:
+            pass
     if verbose:
         print(f"kernel cache: {len(uniq)} schemas, {hits} already cached, {len(uniq) - hits - len(errors)} compiled, "
               f"{len(errors)} failed")

@@ -26,6 +26,21 @@ def _build_native():
     yield
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _warm_kernel_cache(request, _build_native):
+    """GPU runs force the schema-specialised kernels for every test schema.  build() normally left their code
+    objects in pyruhvro_amd/_kcache (they travel with the tree); if the cache is cold on this box, compile them in
+    parallel once (hiprtc, ~30 s, `python -m pyruhvro_amd.prebuild`) instead of one by one inside the tests.  A no-op when everything is cached."""
+    selected_gpu = any(item.get_closest_marker("gpu") for item in request.session.items)
+    if selected_gpu and has_gpu():
+        import subprocess
+        from pyruhvro_amd.prebuild import cache_looks_warm, known_schemas
+        if not cache_looks_warm(known_schemas()):
+            # a fresh interpreter: this process already talks to the GPU and must not be forked
+            subprocess.run([sys.executable, "-m", "pyruhvro_amd.prebuild"], cwd=ROOT, check=True, timeout=900)
+    yield
+
+
 def has_gpu() -> bool:
     try:
         import pyruhvro_amd
