@@ -61,7 +61,11 @@ struct SCtx {
   static constexpr bool kWide = false;   // 32-bit byte offsets into each buffer (host guards: buffers < 4 GiB per chunk)
   mutable uint32_t cnt[K1];                           // per-lane counters (registers)
   mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
-  uint64_t bufs[S::NBUF > 0 ? S::NBUF : 1];           // this chunk's Arrow buffer addresses (uniform)
+  // this chunk's row of the buffer-address table.  Read-only for the whole launch, so it is addressed through the
+  // constant address space: every use is a scalar load the compiler may re-issue instead of keeping (and spilling)
+  // 2 x NBUF SGPRs -- with the addresses held in registers a third of the emit kernel's VALU instructions were
+  // v_readlane reloads of spilled SGPRs.
+  const __attribute__((address_space(4))) uint64_t* bufp;
   uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
   mutable uint32_t nacc[S::NNODES];                   // nulls seen by this wave per node (wave-uniform)
   uint32_t* nullcnt;                                  // LDS [NNODES]
@@ -72,7 +76,7 @@ struct SCtx {
 
   __device__ __forceinline__ uint32_t& counter(int id) const { return cnt[id]; }
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
-  __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
+  __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufp[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { nacc[node] += n; }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
@@ -209,10 +213,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
   // uniform per-workgroup inputs, requested before the window so their latency hides behind it
-  static_for<0, S::NBUF>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    c.bufs[i] = reinterpret_cast<uint64_t>(P.bufptr[(size_t)g.chunk * S::NBUF + i]);
-  });
+  c.bufp = (const __attribute__((address_space(4))) uint64_t*)(reinterpret_cast<uintptr_t>(P.bufptr) + (size_t)g.chunk * S::NBUF * 8);
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
