@@ -53,6 +53,17 @@ __device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uin
   const uint32_t rows = left / TILE;            // wave-uniform
   const uint32_t rem = left - rows * TILE;
   v4u r[KB];
+#ifdef RH_V_STAGE_LANE_PRED
+  // staged for an A/B: one per-lane bound instead of a scalar row test plus a last-row lane
+  // test per row -- the scalar form costs ~12 scalar instructions per row and side (tools/isa_hist.py: 289 SALU)
+  const uint32_t nv = rows + (tid < rem ? 1u : 0u);
+#pragma unroll
+  for (int j = 0; j < KB; j++)
+    if ((uint32_t)j < nv) r[j] = gp[j * TILE];
+#pragma unroll
+  for (int j = 0; j < KB; j++)
+    if ((uint32_t)j < nv) lp[j * TILE] = r[j];
+#else
 #pragma unroll
   for (int j = 0; j < KB; j++) {
     if ((uint32_t)j < rows) r[j] = gp[j * TILE];
@@ -63,6 +74,7 @@ __device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uin
     if ((uint32_t)j < rows) lp[j * TILE] = r[j];
     else if ((uint32_t)j == rows && tid < rem) lp[j * TILE] = r[j];
   }
+#endif
 }
 
 // Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction): one HBM round trip

@@ -258,7 +258,16 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       constexpr int k = decltype(ik)::value;
       if constexpr (NW > 1) {
         uint32_t pre = 0;
+#ifdef RH_V_PREFIX_SELECT
+        // staged for an A/B: read the wave totals unconditionally and select, instead of a predicated LDS read each
+#pragma unroll
+        for (int w = 0; w < NW - 1; w++) {
+          const uint32_t t = s.wtot[k * NW + w];
+          pre += (int)wave > w ? t : 0u;
+        }
+#else
         for (int w = 0; w < NW - 1; w++) pre += (int)wave > w ? s.wtot[k * NW + w] : 0u;
+#endif
         c.cnt[k] += pre;
       }
     });

@@ -232,6 +232,17 @@ __device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_
   }
 }
 
+// Staged for an A/B (RUHVRO_HIP_VARIANT=EMIT_TRUST): the emit kernel only takes the fast walk
+// for tiles whose size pass (same predicates, same bytes) met no anomaly in any lane (tileflag bit 1 clear), so in
+// <EMIT, !CAREFUL> the anomaly predicates are dead weight: reject() and everything that only feeds it drop out.
+#ifdef RH_V_EMIT_TRUST
+#define RH_TRUST (EMIT && !CAREFUL)
+#define RH_REJECT(L, ...) do { if constexpr (!RH_TRUST) reject<CAREFUL>(L, __VA_ARGS__); } while (0)
+#else
+#define RH_TRUST false
+#define RH_REJECT(L, ...) reject<CAREFUL>(L, __VA_ARGS__)
+#endif
+
 // --------------------------------------------------------------------------
 // primitive readers (fast_decode.rs:845-922)
 //
@@ -309,7 +320,7 @@ __device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nul
 // Head of a field for the lanes with `dec`: an optional single-byte null-union branch and an optional
 // varint (`wide`: may need more than 28 bits).  Returns isval (false for lanes without `dec`); v is the
 // varint when isval && want_varint.  L.cur moves past what was read.
-template <bool CAREFUL, class Src>
+template <bool CAREFUL, bool TRUST = false, class Src>
 __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
                                          bool wide, int64_t& v) {
   if (!nullable && !want_varint) return dec;
@@ -339,6 +350,10 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   }
   const bool slow = dec && (!okb || (isval && !okv));
   uint32_t adv = skip + ((isval && want_varint) ? n : 0u);
+  if (TRUST) {               // the size pass saw okb && okv on every lane of this tile: `slow` is dead
+    L.cur += dec ? adv : 0u;
+    return isval;
+  }
   if (CAREFUL) {
     if (__any(slow)) {
       if (slow) {
@@ -395,7 +410,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
   const bool dec = act && L.pres;
   const bool is_int = op.a == FK_I32 || op.a == FK_I64;
   int64_t v = 0;
-  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
                                         op.a == FK_I64, v);
   uint64_t bits;
   bool valid;
@@ -410,8 +425,8 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     const bool eob = want && avail < need;
     bits = op.a == FK_F32 ? (uint64_t)(uint32_t)x : op.a == FK_F64 ? x : (x & 0xFFu);
     const bool badb = want && !eob && op.a == FK_BOOL && bits > 1;   // read_bool, 893-900
-    reject<CAREFUL>(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
-    reject<CAREFUL>(L, badb, E_BOOL, (int64_t)bits);
+    RH_REJECT(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
+    RH_REJECT(L, badb, E_BOOL, (int64_t)bits);
     valid = want && L.live;
     L.cur += valid ? need : 0u;
   }
@@ -440,21 +455,21 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   const bool act = L.live;
   const bool dec = act && L.pres;
   int64_t v = 0;
-  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   if (op.code == OP_STRING) {
     // the fast walk only ever sees lengths from the 28-bit single-read decode: 32-bit compares are enough there
     const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
     const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur);
-    reject<CAREFUL>(L, neg, E_NEGLEN);
-    reject<CAREFUL>(L, eob, E_EOB_STR);
+    RH_REJECT(L, neg, E_NEGLEN);
+    RH_REJECT(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
     spos = L.cur;
     L.cur += len;
   } else {
     const bool oor = want && (CAREFUL ? (uint64_t)v >= (uint64_t)op.c : (uint32_t)v >= (uint32_t)op.c);
-    reject<CAREFUL>(L, oor, E_ENUM, v);
+    RH_REJECT(L, oor, E_ENUM, v);
     if (want && L.live) {
       spos = c.sym_off[op.b + (int32_t)v];
       len = c.sym_off[op.b + (int32_t)v + 1] - spos;
@@ -494,7 +509,7 @@ __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& 
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head<CAREFUL>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.pres = valid;
@@ -512,9 +527,9 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   L.sstk = (L.sstk << 8) | 0xFFull;
   const bool dec = act && L.pres;
   int64_t idx = 0;
-  const bool got = read_head<CAREFUL>(src, L, dec, false, false, true, false, idx) && L.live;
+  const bool got = read_head<CAREFUL, RH_TRUST>(src, L, dec, false, false, true, false, idx) && L.live;
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
-  reject<CAREFUL>(L, oor, E_UNION, idx);
+  RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
   if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
   if (EMIT && act) st_global<int8_t, Ctx::kWide>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
@@ -536,7 +551,7 @@ __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane&
   L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head<CAREFUL>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.live = valid;      // only rows that really carry a list enter the block loop
@@ -575,10 +590,22 @@ __device__ __forceinline__ void list_next_slow(const Ctx& c, const Src& src, Lan
 }
 
 // Head of the block loop.  Returns true while any lane of the wave still has an item (wave-uniform).
-template <bool CAREFUL, class Src, class Ctx>
+template <bool CAREFUL, bool TRUST = false, class Src, class Ctx>
 __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   uint32_t& rm = c.remaining(op.c);
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
+  if (TRUST) {               // every block header of this tile took the one-read form below in the size pass, unclamped
+    uint32_t raw, n;
+    (void)varint32((uint32_t)src.ld5(L.cur), 4u, raw, n);
+    if (need) {
+      L.cur += n;
+      if ((raw >> 1) == 0) L.live = false;
+      else rm = raw >> 1;
+    }
+    if (!__any(L.live)) return false;
+    L.pres = L.live;
+    return true;
+  }
   // common wire form: a small positive count, or the 0 terminator, in one byte..four bytes
   const uint64_t x = src.ld5(L.cur);
   uint32_t raw, n;

@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--kernel", default="emit", choices=sorted(KERNELS))
     ap.add_argument("--fast-only", action="store_true")
     ap.add_argument("--lines", type=int, default=0, help="also print the N hottest source lines")
+    ap.add_argument("--variant", default="", help="RUHVRO_HIP_VARIANT names (staged experimental code paths), comma separated")
     args = ap.parse_args()
+    if args.variant:
+        os.environ["RUHVRO_HIP_VARIANT"] = args.variant
     from avrogen.schemas import SCHEMAS
     from pyruhvro_amd import cabi
     schema = SCHEMAS.get(args.schema) or open(args.schema).read()
@@ -90,7 +93,7 @@ def main():
         if l.startswith(kern + ":"):
             inside = True
             continue
-        if inside and re.match(r"\s*s_endpgm", l):
+        if inside and re.match(r"\.Lfunc_end|\s*\.size\s+" + kern, l):      # (a kernel may hold several s_endpgm)
             break
         if not inside:
             continue
@@ -111,7 +114,8 @@ def main():
         a[1 if t.startswith("v_") else 2 if t.startswith("s_") else 3 if t.startswith("ds_") else 4] += 1
         by_line[cur] += 1
         ops[t.split()[0]] += 1
-    print(f"# {kern}, schema {args.schema}{', fast walk only' if args.fast_only else ''}: static instructions per source function")
+    print(f"# {kern}, schema {args.schema}{', fast walk only' if args.fast_only else ''}"
+          f"{', variant ' + args.variant if args.variant else ''}: static instructions per source function")
     print("%-58s %6s %6s %6s %5s %5s" % ("where", "total", "VALU", "SALU", "DS", "VMEM"))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         print("%-58s %6d %6d %6d %5d %5d" % (k[:58], *v))
