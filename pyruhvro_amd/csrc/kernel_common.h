@@ -48,10 +48,49 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) 
 // last, partial row is predicated.  Deliberately NOT a loop: with a loop the register array is loop-carried and
 // the compiler protects each element with an s_waitcnt vmcnt(0) BEFORE re-loading it, which serialises every
 // load behind the previous one's HBM round trip (seen in the ISA; it made this phase 13.5k cycles per wave).
+#ifdef RH_V_STAGE_SWITCH
+// staged for an A/B: exactly ROWS unpredicated rows + the partial row, selected by a scalar
+// switch on the row count -- the executed path is ~2 instructions per row instead of ~24 (tools/isa_hist.py: the
+// staging is 29 % of the size kernel's instructions and 13 % of the emit kernel's)
+template <int TILE, int ROWS>
+__device__ __forceinline__ void stage_exact(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t rem, uint32_t tid) {
+  // uniform base + 32-bit lane offset: the loads take the scalar-base addressing form, one v_add per row
+  const uintptr_t base = reinterpret_cast<uintptr_t>(gp - tid);
+  const uint32_t voff = tid * 16u;
+  v4u r[ROWS + 1];
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) r[j] = *reinterpret_cast<const RH_GLOBAL v4u*>(base + (voff + (uint32_t)j * (TILE * 16u)));
+  const bool part = tid < rem;
+  if (part) r[ROWS] = *reinterpret_cast<const RH_GLOBAL v4u*>(base + (voff + (uint32_t)ROWS * (TILE * 16u)));
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) lp[j * TILE] = r[j];
+  if (part) lp[ROWS * TILE] = r[ROWS];
+}
+#endif
+
 template <int TILE, int KB>
 __device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t left, uint32_t tid) {
   const uint32_t rows = left / TILE;            // wave-uniform
   const uint32_t rem = left - rows * TILE;
+#ifdef RH_V_STAGE_SWITCH
+  static_assert(KB == 12, "the switch below lists 0..12 rows");
+  switch (__builtin_amdgcn_readfirstlane(rows)) {
+    case 0: stage_exact<TILE, 0>(gp, lp, rem, tid); break;
+    case 1: stage_exact<TILE, 1>(gp, lp, rem, tid); break;
+    case 2: stage_exact<TILE, 2>(gp, lp, rem, tid); break;
+    case 3: stage_exact<TILE, 3>(gp, lp, rem, tid); break;
+    case 4: stage_exact<TILE, 4>(gp, lp, rem, tid); break;
+    case 5: stage_exact<TILE, 5>(gp, lp, rem, tid); break;
+    case 6: stage_exact<TILE, 6>(gp, lp, rem, tid); break;
+    case 7: stage_exact<TILE, 7>(gp, lp, rem, tid); break;
+    case 8: stage_exact<TILE, 8>(gp, lp, rem, tid); break;
+    case 9: stage_exact<TILE, 9>(gp, lp, rem, tid); break;
+    case 10: stage_exact<TILE, 10>(gp, lp, rem, tid); break;
+    case 11: stage_exact<TILE, 11>(gp, lp, rem, tid); break;
+    default: stage_exact<TILE, 12>(gp, lp, 0u, tid); break;     // left <= KB * TILE: 12 full rows, no partial one
+  }
+  return;
+#endif
   v4u r[KB];
 #ifdef RH_V_STAGE_LANE_PRED
   // staged for an A/B: one per-lane bound instead of a scalar row test plus a last-row lane

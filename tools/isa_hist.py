@@ -65,6 +65,7 @@ def main():
             p = os.path.join(tmp, "spec_body.h")
             s = open(p).read()
             s = s.replace("if (rewalk) {", "if (false) {")
+            s = s.replace("  if (__any(L.redo)) {   //", "  if (false) {   //")      # k_size: no careful re-walk of the wave
             s = s.replace("  if (careful) {\n    spec_run_walk<S, true, true>", "  if (false) {\n    spec_run_walk<S, true, true>")
             s = s.replace("  if (fits) {\n    LdsSrc src{win};\n    S::template walk<EMIT, CAREFUL>(c, src, L);\n  } else {\n"
                           "    GlobalSrc src{P.data + wb16, P.data_len - wb16};\n    S::template walk<EMIT, true>(c, src, L);\n  }",
