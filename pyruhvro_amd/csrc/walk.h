@@ -149,6 +149,43 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
 }
 
+#ifdef RH_V_COPY_FLAT
+// staged for an A/B: the same store plan, but the second (tail) store of every length class is
+// unconditional -- when the length equals the class width it rewrites the bytes the first store wrote.  The inner
+// `if (len > w)` regions cost 3-4 scalar instructions each and are almost always taken by some lane of the wave.
+template <bool WIDE, class Src>
+__device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
+  if (len >= 16) {
+    uint32_t j = 0;
+    for (; j + 32 <= len; j += 32) {
+      const v4w x0 = s.ld16(sp + j), x1 = s.ld16(sp + j + 16);
+      st_at<v4wu, WIDE>(base, d + j, x0);
+      st_at<v4wu, WIDE>(base, d + j + 16, x1);
+    }
+    if (j < len) {   // 1..31 bytes left: [j, j+16) if it fits, then the last 16
+      const uint32_t a = j + 16 <= len ? j : len - 16;
+      const v4w x0 = s.ld16(sp + a), x1 = s.ld16(sp + len - 16);
+      st_at<v4wu, WIDE>(base, d + a, x0);
+      st_at<v4wu, WIDE>(base, d + len - 16, x1);
+    }
+  } else if (len >= 8) {
+    const uint64_t x0 = s.ld8(sp), x1 = s.ld8(sp + len - 8);
+    st_at<u64u, WIDE>(base, d, x0);
+    st_at<u64u, WIDE>(base, d + len - 8, x1);
+  } else {
+    const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
+    if (len >= 4) {
+      st_at<u32u, WIDE>(base, d, (uint32_t)x);
+      st_at<u32u, WIDE>(base, d + len - 4, (uint32_t)(x >> (8 * (len - 4))));
+    } else if (len >= 2) {
+      st_at<u16u, WIDE>(base, d, (uint16_t)x);
+      st_at<u16u, WIDE>(base, d + len - 2, (uint16_t)(x >> (8 * (len - 2))));
+    } else {
+      st_at<uint8_t, WIDE>(base, d, (uint8_t)x);
+    }
+  }
+}
+#else
 template <bool WIDE, class Src>
 __device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
   if (len >= 16) {
@@ -181,6 +218,8 @@ __device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s,
     }
   }
 }
+
+#endif
 
 template <class D>
 __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len) {
