@@ -54,3 +54,29 @@ def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
 def test_unsupported_schema_has_no_kernel():
     with pytest.raises(ValueError):
         cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":"bytes"}]}')
+
+
+STAGED_VARIANTS = "EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT"
+
+
+def test_staged_kernel_variants_compile_and_are_keyed_apart(tmp_path, monkeypatch):
+    """RUHVRO_HIP_VARIANT only prepends `#define RH_V_<NAME> 1` lines to the generated source (experimental code
+    paths staged in the device headers for an A/B on the GPU).  They must at least compile for
+    gfx950, live under their own cache keys, and leave the default source untouched."""
+    monkeypatch.setenv("RUHVRO_HIP_KERNEL_CACHE", str(tmp_path))
+    schema = SCHEMAS["array_and_map"]
+    monkeypatch.delenv("RUHVRO_HIP_VARIANT", raising=False)
+    base_src = cabi.kernel_source(schema)
+    assert "RH_V_" not in base_src
+    assert cabi.prebuild(schema) is False
+    n_default = len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")])
+    monkeypatch.setenv("RUHVRO_HIP_VARIANT", STAGED_VARIANTS)
+    var_src = cabi.kernel_source(schema)
+    for name in STAGED_VARIANTS.split(","):
+        assert f"#define RH_V_{name} 1" in var_src
+    assert var_src.replace("".join(f"#define RH_V_{n} 1\n" for n in STAGED_VARIANTS.split(",")), "") \
+        .replace("h_list_next<CAREFUL, (EMIT && !CAREFUL)>", "h_list_next<CAREFUL>") == base_src
+    assert cabi.prebuild(schema) is False                      # compiled now, under other keys
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2 * n_default
+    monkeypatch.setenv("RUHVRO_HIP_VARIANT", "not a name,lower,OK_1")
+    assert "RH_V_OK_1" in cabi.kernel_source(schema) and "lower" not in cabi.kernel_source(schema)
