@@ -26,7 +26,8 @@ def _cache_dir() -> str:
 
 def _marker(schemas: List[str]) -> str:
     import hashlib
-    h = hashlib.sha1("\0".join(sorted(schemas)).encode()).hexdigest()[:16]
+    variant = os.environ.get("RUHVRO_HIP_VARIANT", "")      # staged kernel variants have their own code objects
+    h = hashlib.sha1(("\0".join(sorted(schemas)) + "\1" + variant).encode()).hexdigest()[:16]
     return os.path.join(_cache_dir(), f"warm_{h}.ok")
 
 
