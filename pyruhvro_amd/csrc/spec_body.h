@@ -78,7 +78,14 @@ struct SCtx {
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufp[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
+#ifdef RH_V_NACC_LDS
+  // staged for an A/B: no per-node accumulators (NNODES wave-uniform registers that spill): one LDS add per field
+  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
+    if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
+  }
+#else
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { nacc[node] += n; }
+#endif
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
 
