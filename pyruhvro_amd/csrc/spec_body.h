@@ -122,8 +122,16 @@ struct SpecSmem {
 template <class S, bool EMIT, bool CAREFUL>
 __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
+#ifdef RH_V_CUR_ABS
+    const uint32_t bias = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)win;   // LDS address of the window
+    L.cur += bias; L.end += bias;
+    LdsAbsSrc src;
+    S::template walk<EMIT, CAREFUL>(c, src, L);
+    L.cur -= bias; L.end -= bias;
+#else
     LdsSrc src{win};
     S::template walk<EMIT, CAREFUL>(c, src, L);
+#endif
   } else {
     GlobalSrc src{P.data + wb16, P.data_len - wb16};
     S::template walk<EMIT, true>(c, src, L);

@@ -96,6 +96,44 @@ struct LdsSrc {
   }
 };
 
+#ifdef RH_V_CUR_ABS
+// staged for an A/B: cursors hold ABSOLUTE LDS addresses, so a read is (p & ~3) straight into ds_read -- through
+// LdsSrc every read adds the window symbol's address (a link-time constant the compiler cannot fold: one
+// `v_add_u32 v, 0, v` per read, tools/isa_hist.py)
+struct LdsAbsSrc {
+  typedef const __attribute__((address_space(3))) uint32_t* lp32;
+  typedef const __attribute__((address_space(3))) uint8_t* lp8;
+  __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return *(lp8)p; }
+  __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
+    lp32 a = (lp32)(p & ~3u);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ v4w ld16(uint32_t p) const {
+    lp32 a = (lp32)(p & ~3u);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+    const uint32_t sh = p & 3u;
+    v4w r;
+    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    r.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    return r;
+  }
+  __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
+    lp32 a = (lp32)(p & ~3u);
+    const uint32_t d0 = a[0], d1 = a[1];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
+};
+#endif
+
 struct GlobalSrc {
   const uint8_t* g;   // payload + window base
   uint64_t lim;       // readable bytes from g

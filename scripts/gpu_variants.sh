@@ -1,14 +1,14 @@
 #!/bin/bash
 # A/B of the staged kernel variants on the GPU box.  Before sending the tree, prebuild the
 # variant kernels HERE so the box only loads code objects:
-#     for v in "" EMIT_TRUST STAGE_SWITCH PREFIX_SELECT COPY_FLAT EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT; do
+#     for v in "" EMIT_TRUST STAGE_SWITCH STAGE_LANE_PRED PREFIX_SELECT COPY_FLAT NACC_LDS CUR_ABS EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT; do
 #         RUHVRO_HIP_VARIANT=$v python -m pyruhvro_amd.prebuild; done
 # Usage on the box:  bash scripts/gpu_variants.sh [tag] [variant ...]     (default: each staged variant, then all)
 TAG=${1:-variants}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 VARS=("$@")
-if [ ${#VARS[@]} -eq 0 ]; then VARS=("" EMIT_TRUST STAGE_SWITCH PREFIX_SELECT COPY_FLAT "EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT"); fi
+if [ ${#VARS[@]} -eq 0 ]; then VARS=("" EMIT_TRUST STAGE_SWITCH STAGE_LANE_PRED PREFIX_SELECT COPY_FLAT NACC_LDS CUR_ABS "EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT"); fi
 for v in "${VARS[@]}"; do
   name=${v:-default}; name=${name//,/+}
   export RUHVRO_HIP_VARIANT=$v

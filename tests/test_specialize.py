@@ -56,7 +56,7 @@ def test_unsupported_schema_has_no_kernel():
         cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":"bytes"}]}')
 
 
-STAGED_VARIANTS = "EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT"
+STAGED_VARIANTS = "EMIT_TRUST,STAGE_SWITCH,PREFIX_SELECT,COPY_FLAT,NACC_LDS,CUR_ABS"
 
 
 def test_staged_kernel_variants_compile_and_are_keyed_apart(tmp_path, monkeypatch):

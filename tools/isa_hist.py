@@ -67,7 +67,7 @@ def main():
             s = s.replace("if (rewalk) {", "if (false) {")
             s = s.replace("  if (__any(L.redo)) {   //", "  if (false) {   //")      # k_size: no careful re-walk of the wave
             s = s.replace("  if (careful) {\n    spec_run_walk<S, true, true>", "  if (false) {\n    spec_run_walk<S, true, true>")
-            s, n = re.subn(r"  if \(fits\) \{\n(    LdsSrc src\{[^\n]*\n    S::template walk<EMIT, CAREFUL>\(c, src, L\);\n)  \} else \{\n"
+            s, n = re.subn(r"  if \(fits\) \{\n((?:[^\n]*\n)*?)  \} else \{\n"
                            r"    GlobalSrc src\{[^\n]*\n    S::template walk<EMIT, true>\(c, src, L\);\n  \}",
                            r"  {\n\1  }", s)
             assert n == 1, "spec_run_walk changed: update tools/isa_hist.py"
