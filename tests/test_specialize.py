@@ -80,3 +80,44 @@ def test_staged_kernel_variants_compile_and_are_keyed_apart(tmp_path, monkeypatc
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2 * n_default
     monkeypatch.setenv("RUHVRO_HIP_VARIANT", "not a name,lower,OK_1")
     assert "RH_V_OK_1" in cabi.kernel_source(schema) and "lower" not in cabi.kernel_source(schema)
+
+
+def _kernel_notes(hsaco_path):
+    """{kernel name: {metadata key: int}} from the code object's AMDGPU notes."""
+    import re
+    import subprocess
+    exe = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(exe):
+        pytest.skip("llvm-readelf not available")
+    txt = subprocess.run([exe, "--notes", hsaco_path], capture_output=True, text=True, check=True).stdout
+    out, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s*\.(\w+):\s+(\d+)\s*$", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_specialised_kernels_of_the_benchmark_schema_stay_in_registers(tmp_path, monkeypatch):
+    """Resource guard for the headline kernels (BASELINE config 4 schema): no scratch, no VGPR spills, VGPR counts
+    that keep 4 workgroups of 4 waves per CU resident (LDS-bound), and the emit kernel's SGPR spills well under the
+    194 it had while the 40 buffer addresses lived in SGPRs (every spill reload is a VALU instruction and the kernel
+    is VALU-bound -- DESIGN.md section 5)."""
+    monkeypatch.setenv("RUHVRO_HIP_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.delenv("RUHVRO_HIP_VARIANT", raising=False)
+    cabi.prebuild(SCHEMAS["full"])
+    notes = {}
+    for f in os.listdir(tmp_path):
+        if f.endswith(".hsaco"):
+            notes.update(_kernel_notes(os.path.join(tmp_path, f)))
+    assert set(notes) >= {"rh_spec_size", "rh_spec_emit", "rh_espec_size", "rh_espec_emit"}
+    for name, md in notes.items():
+        assert md["private_segment_fixed_size"] == 0, (name, md)
+        assert md["vgpr_spill_count"] == 0, (name, md)
+        assert md["vgpr_count"] <= 128, (name, md)
+    assert notes["rh_spec_emit"]["sgpr_spill_count"] <= 110, notes["rh_spec_emit"]
+    assert notes["rh_spec_size"]["sgpr_spill_count"] == 0 and notes["rh_espec_emit"]["sgpr_spill_count"] == 0
