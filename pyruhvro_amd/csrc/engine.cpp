@@ -26,6 +26,7 @@
 #include "program.h"
 #include "schema.h"
 #include "specialize.h"
+#include "encode.h"
 
 extern "C" {
 int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream);
@@ -35,6 +36,10 @@ int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDe
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
+// Arrow -> Avro kernels (encode.hip)
+int rh_launch_esize(const rh::EParams* P, uint32_t lds_bytes, void* stream);
+int rh_launch_eemit(const rh::EParams* P, uint32_t lds_bytes, void* stream);
+uint32_t rh_enc_lds_bytes(int ndom, int list_depth);
 }
 #include <memory>
 
@@ -1149,13 +1154,6 @@ int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* le
 // ===========================================================================
 // Arrow -> Avro: rh_encode
 // ===========================================================================
-#include "encode.h"
-
-extern "C" {
-int rh_launch_esize(const rh::EParams* P, uint32_t lds_bytes, void* stream);
-int rh_launch_eemit(const rh::EParams* P, uint32_t lds_bytes, void* stream);
-uint32_t rh_enc_lds_bytes(int ndom, int list_depth);
-}
 
 namespace {
 
