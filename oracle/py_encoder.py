@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, not product code) -- Arrow -> Avro encoder.
 
-Pure-Python restatement of the reference's fast encode path, the next row of SURVEY.md section 8(f)
-(N1, not yet built on the GPU):
+Pure-Python restatement of the reference's fast encode path, SURVEY.md section 8(f) N1 -- the checker of the GPU
+path behind pyruhvro_amd.serialize_record_batch (rh_encode; tests/test_gpu_encode.py):
 
   ruhvro/src/fast_encode.rs:27-53     serialize_chunk: one datum per row into a BinaryArray
   ruhvro/src/fast_encode.rs:151-385   encoder construction: columns matched BY NAME, 2-variant null unions

@@ -1,6 +1,6 @@
 """The encode oracle (oracle/py_encoder.py: restatement of ruhvro/src/fast_encode.rs + serialize.rs chunking),
-pinned against the decode oracle, the test encoder and the reference's golden datums.  CPU only; it prepares the
-next SURVEY 8(f) row (GPU Arrow -> Avro), which is not built yet."""
+pinned against the decode oracle, the test encoder and the reference's golden datums.  CPU only; the GPU path it
+checks (rh_encode) is compared with it in tests/test_gpu_encode.py."""
 import json
 import os
 
