@@ -48,10 +48,9 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) 
 // last, partial row is predicated.  Deliberately NOT a loop: with a loop the register array is loop-carried and
 // the compiler protects each element with an s_waitcnt vmcnt(0) BEFORE re-loading it, which serialises every
 // load behind the previous one's HBM round trip (seen in the ISA; it made this phase 13.5k cycles per wave).
-#ifdef RH_V_STAGE_SWITCH
-// staged for an A/B: exactly ROWS unpredicated rows + the partial row, selected by a scalar
-// switch on the row count -- the executed path is ~2 instructions per row instead of ~24 (tools/isa_hist.py: the
-// staging is 29 % of the size kernel's instructions and 13 % of the emit kernel's)
+// Exactly ROWS unpredicated rows + the partial row, selected by a scalar switch on the row count: the executed path
+// is ~2 instructions per row instead of the ~24 of a per-row scalar row test + last-row lane test
+// (k_emit 0.950 -> 0.940 ms, profiles/r02a_variants_ab.txt).
 template <int TILE, int ROWS>
 __device__ __forceinline__ void stage_exact(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t rem, uint32_t tid) {
   // uniform base + 32-bit lane offset: the loads take the scalar-base addressing form, one v_add per row
@@ -66,13 +65,11 @@ __device__ __forceinline__ void stage_exact(const RH_GLOBAL v4u* gp, v4u* lp, ui
   for (int j = 0; j < ROWS; j++) lp[j * TILE] = r[j];
   if (part) lp[ROWS * TILE] = r[ROWS];
 }
-#endif
 
 template <int TILE, int KB>
 __device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t left, uint32_t tid) {
   const uint32_t rows = left / TILE;            // wave-uniform
   const uint32_t rem = left - rows * TILE;
-#ifdef RH_V_STAGE_SWITCH
   static_assert(KB == 12, "the switch below lists 0..12 rows");
   switch (__builtin_amdgcn_readfirstlane(rows)) {
     case 0: stage_exact<TILE, 0>(gp, lp, rem, tid); break;
@@ -89,31 +86,6 @@ __device__ __forceinline__ void stage_rows(const RH_GLOBAL v4u* gp, v4u* lp, uin
     case 11: stage_exact<TILE, 11>(gp, lp, rem, tid); break;
     default: stage_exact<TILE, 12>(gp, lp, 0u, tid); break;     // left <= KB * TILE: 12 full rows, no partial one
   }
-  return;
-#endif
-  v4u r[KB];
-#ifdef RH_V_STAGE_LANE_PRED
-  // staged for an A/B: one per-lane bound instead of a scalar row test plus a last-row lane
-  // test per row -- the scalar form costs ~12 scalar instructions per row and side (tools/isa_hist.py: 289 SALU)
-  const uint32_t nv = rows + (tid < rem ? 1u : 0u);
-#pragma unroll
-  for (int j = 0; j < KB; j++)
-    if ((uint32_t)j < nv) r[j] = gp[j * TILE];
-#pragma unroll
-  for (int j = 0; j < KB; j++)
-    if ((uint32_t)j < nv) lp[j * TILE] = r[j];
-#else
-#pragma unroll
-  for (int j = 0; j < KB; j++) {
-    if ((uint32_t)j < rows) r[j] = gp[j * TILE];
-    else if ((uint32_t)j == rows && tid < rem) r[j] = gp[j * TILE];
-  }
-#pragma unroll
-  for (int j = 0; j < KB; j++) {
-    if ((uint32_t)j < rows) lp[j * TILE] = r[j];
-    else if ((uint32_t)j == rows && tid < rem) lp[j * TILE] = r[j];
-  }
-#endif
 }
 
 // Stage [wb16, we) of the payload into LDS with 16-byte loads (1 KiB per wave instruction): one HBM round trip

@@ -67,7 +67,6 @@ struct SCtx {
   // v_readlane reloads of spilled SGPRs.
   const __attribute__((address_space(4))) uint64_t* bufp;
   uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
-  mutable uint32_t nacc[S::NNODES];                   // nulls seen by this wave per node (wave-uniform)
   uint32_t* nullcnt;                                  // LDS [NNODES]
   const uint32_t* sym_off;
   const uint8_t* sym_data;
@@ -78,14 +77,11 @@ struct SCtx {
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufp[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
-#ifdef RH_V_NACC_LDS
-  // staged for an A/B: no per-node accumulators (NNODES wave-uniform registers that spill): one LDS add per field
+  // no per-node accumulators (NNODES wave-uniform registers that spill): one LDS add per field and wave
+  // (k_emit 0.950 -> 0.937 ms, profiles/r02a_variants_ab.txt)
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
   }
-#else
-  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { nacc[node] += n; }
-#endif
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
 };
 
@@ -122,16 +118,8 @@ struct SpecSmem {
 template <class S, bool EMIT, bool CAREFUL>
 __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
-#ifdef RH_V_CUR_ABS
-    const uint32_t bias = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)win;   // LDS address of the window
-    L.cur += bias; L.end += bias;
-    LdsAbsSrc src;
-    S::template walk<EMIT, CAREFUL>(c, src, L);
-    L.cur -= bias; L.end -= bias;
-#else
     LdsSrc src{win};
     S::template walk<EMIT, CAREFUL>(c, src, L);
-#endif
   } else {
     GlobalSrc src{P.data + wb16, P.data_len - wb16};
     S::template walk<EMIT, true>(c, src, L);
@@ -142,7 +130,6 @@ template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
   static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
-  static_for<0, S::NNODES>([&](auto in) { c.nacc[decltype(in)::value] = 0; });
   c.nullcnt = s.nullcnt; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
 }
@@ -273,16 +260,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       constexpr int k = decltype(ik)::value;
       if constexpr (NW > 1) {
         uint32_t pre = 0;
-#ifdef RH_V_PREFIX_SELECT
-        // staged for an A/B: read the wave totals unconditionally and select, instead of a predicated LDS read each
-#pragma unroll
-        for (int w = 0; w < NW - 1; w++) {
-          const uint32_t t = s.wtot[k * NW + w];
-          pre += (int)wave > w ? t : 0u;
-        }
-#else
         for (int w = 0; w < NW - 1; w++) pre += (int)wave > w ? s.wtot[k * NW + w] : 0u;
-#endif
         c.cnt[k] += pre;
       }
     });
@@ -298,12 +276,6 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     if (L.redo) L.err = E_INTERNAL;   // k_size walks the same bytes and would have flagged the tile
   }
   RH_MARK(7);
-  if (lane == 0)
-    static_for<0, S::NNODES>([&](auto in) {
-      constexpr int i = decltype(in)::value;
-      if (c.nacc[i]) atomicAdd(&s.nullcnt[i], c.nacc[i]);
-    });
-
   report_errors(P, s.misc, L, g, tid, tile);   // barrier inside: nullcnt + staging complete
   RH_MARK(8);
   for (int i = tid; i < S::NNODES; i += T) {

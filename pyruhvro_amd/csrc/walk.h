@@ -96,44 +96,6 @@ struct LdsSrc {
   }
 };
 
-#ifdef RH_V_CUR_ABS
-// staged for an A/B: cursors hold ABSOLUTE LDS addresses, so a read is (p & ~3) straight into ds_read -- through
-// LdsSrc every read adds the window symbol's address (a link-time constant the compiler cannot fold: one
-// `v_add_u32 v, 0, v` per read, tools/isa_hist.py)
-struct LdsAbsSrc {
-  typedef const __attribute__((address_space(3))) uint32_t* lp32;
-  typedef const __attribute__((address_space(3))) uint8_t* lp8;
-  __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return *(lp8)p; }
-  __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
-    lp32 a = (lp32)(p & ~3u);
-    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
-    const uint32_t sh = p & 3u;
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    return ((uint64_t)hi << 32) | lo;
-  }
-  __device__ __forceinline__ v4w ld16(uint32_t p) const {
-    lp32 a = (lp32)(p & ~3u);
-    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
-    const uint32_t sh = p & 3u;
-    v4w r;
-    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    r.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    return r;
-  }
-  __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
-    lp32 a = (lp32)(p & ~3u);
-    const uint32_t d0 = a[0], d1 = a[1];
-    const uint32_t sh = p & 3u;
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
-    return ((uint64_t)hi << 32) | lo;
-  }
-};
-#endif
-
 struct GlobalSrc {
   const uint8_t* g;   // payload + window base
   uint64_t lim;       // readable bytes from g
@@ -187,43 +149,6 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
 }
 
-#ifdef RH_V_COPY_FLAT
-// staged for an A/B: the same store plan, but the second (tail) store of every length class is
-// unconditional -- when the length equals the class width it rewrites the bytes the first store wrote.  The inner
-// `if (len > w)` regions cost 3-4 scalar instructions each and are almost always taken by some lane of the wave.
-template <bool WIDE, class Src>
-__device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
-  if (len >= 16) {
-    uint32_t j = 0;
-    for (; j + 32 <= len; j += 32) {
-      const v4w x0 = s.ld16(sp + j), x1 = s.ld16(sp + j + 16);
-      st_at<v4wu, WIDE>(base, d + j, x0);
-      st_at<v4wu, WIDE>(base, d + j + 16, x1);
-    }
-    if (j < len) {   // 1..31 bytes left: [j, j+16) if it fits, then the last 16
-      const uint32_t a = j + 16 <= len ? j : len - 16;
-      const v4w x0 = s.ld16(sp + a), x1 = s.ld16(sp + len - 16);
-      st_at<v4wu, WIDE>(base, d + a, x0);
-      st_at<v4wu, WIDE>(base, d + len - 16, x1);
-    }
-  } else if (len >= 8) {
-    const uint64_t x0 = s.ld8(sp), x1 = s.ld8(sp + len - 8);
-    st_at<u64u, WIDE>(base, d, x0);
-    st_at<u64u, WIDE>(base, d + len - 8, x1);
-  } else {
-    const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
-    if (len >= 4) {
-      st_at<u32u, WIDE>(base, d, (uint32_t)x);
-      st_at<u32u, WIDE>(base, d + len - 4, (uint32_t)(x >> (8 * (len - 4))));
-    } else if (len >= 2) {
-      st_at<u16u, WIDE>(base, d, (uint16_t)x);
-      st_at<u16u, WIDE>(base, d + len - 2, (uint16_t)(x >> (8 * (len - 2))));
-    } else {
-      st_at<uint8_t, WIDE>(base, d, (uint8_t)x);
-    }
-  }
-}
-#else
 template <bool WIDE, class Src>
 __device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
   if (len >= 16) {
@@ -256,8 +181,6 @@ __device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s,
     }
   }
 }
-
-#endif
 
 template <class D>
 __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len) {
@@ -309,16 +232,11 @@ __device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_
   }
 }
 
-// Staged for an A/B (RUHVRO_HIP_VARIANT=EMIT_TRUST): the emit kernel only takes the fast walk
-// for tiles whose size pass (same predicates, same bytes) met no anomaly in any lane (tileflag bit 1 clear), so in
-// <EMIT, !CAREFUL> the anomaly predicates are dead weight: reject() and everything that only feeds it drop out.
-#ifdef RH_V_EMIT_TRUST
+// The emit kernel only takes the fast walk for tiles whose size pass (same predicates, same bytes) met no anomaly in
+// any lane (tileflag bit 1 clear), so in <EMIT, !CAREFUL> the anomaly predicates are dead weight: reject() and
+// everything that only feeds it drop out (measured on MI355X: k_emit 0.950 -> 0.918 ms, profiles/r02a_variants_ab.txt).
 #define RH_TRUST (EMIT && !CAREFUL)
 #define RH_REJECT(L, ...) do { if constexpr (!RH_TRUST) reject<CAREFUL>(L, __VA_ARGS__); } while (0)
-#else
-#define RH_TRUST false
-#define RH_REJECT(L, ...) reject<CAREFUL>(L, __VA_ARGS__)
-#endif
 
 // --------------------------------------------------------------------------
 // primitive readers (fast_decode.rs:845-922)
