@@ -8,8 +8,13 @@
 A step = one pass of the hot path (k_size -> k_scan -> k_emit, C ABI rh_decode_device) over one batch of
 synthetic Avro records that is ALREADY resident in HBM; the Arrow buffers are produced in HBM.  Workload
 (BASELINE.json config 4, the one the metric's target is quoted on): 10,000,000 records of the
-scripts/generate_avro.py schema, num_chunks = 8, per GPU (weak scaling: rank r decodes rows
-[r*10M, (r+1)*10M) of the seeded stream; no data-path collective -- records are independent).
+scripts/generate_avro.py schema, num_chunks = 8.
+
+N > 1 (BASELINE.json config 5): the SAME seeded 10M-record list, its 8 reference chunks
+(ruhvro/src/deserialize.rs:57-68) dealt to the ranks in contiguous runs (rh_shard_chunks: rank r of N decodes chunks
+[r*8/N, (r+1)*8/N)), so every batch is produced by one GPU -- "scaling": "strong", total work fixed.  No data-path
+collective: records are independent; RCCL carries the barrier, the MAX over rank times and the stats all-gather.
+`--scaling weak` keeps round 1's mode (every rank decodes its own 10M records of the stream).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      k_emit (the dominant kernel): algorithmic bytes per launch / its mean launch duration,
@@ -50,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = one list, whole chunks dealt to the ranks (BASELINE config 5); weak = the list per rank")
     return ap.parse_args(argv)
 
 
@@ -104,8 +111,13 @@ def run(args, make_step=None, backend="nccl"):
     gen_cfg, n, num_chunks, desc = WORKLOADS[args.workload]
     if args.records:
         n = args.records
-    lo, _ = rdist.shard_rows(n, rank)
-    step, info = make_step(gen_cfg, n, lo, num_chunks, dev, local_rank)
+    if getattr(args, "scaling", "weak") == "strong":
+        # one list of n records, k reference chunks; this rank owns whole chunks [c0, c1) = rows [lo, hi)
+        shard = rdist.strong_shard(n, num_chunks, world, rank)
+    else:
+        lo, hi = rdist.shard_rows(n, rank)
+        shard = {"row_lo": lo, "rows": n, "chunks": min(num_chunks, max(n, 1)), "chunk_rows": 0}
+    step, info = make_step(gen_cfg, shard, dev, local_rank)
 
     def sync():
         if world > 1:
@@ -127,7 +139,7 @@ def run(args, make_step=None, backend="nccl"):
     wall = rdist.max_over_ranks(wall, dev)
 
     run.info = info
-    local = {"records": n, "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
+    local = {"records": shard["rows"], "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
              "step_ms": wall * 1e3 / args.steps}
     for k in acc:
         local[k] = acc[k] / max(args.steps, 1)
@@ -136,14 +148,17 @@ def run(args, make_step=None, backend="nccl"):
     return rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc)
 
 
-def gpu_step_factory(gen_cfg, n, row_lo, num_chunks, dev, local_rank):
+def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     import numpy as np
     import torch
     from avrogen import fastgen
     from avrogen.schemas import SCHEMAS
     from pyruhvro_amd import cabi
 
-    data, offsets = fastgen.generate(gen_cfg, n, start=row_lo)
+    n, num_chunks = shard["rows"], shard["chunks"]
+    data, offsets = fastgen.generate(gen_cfg, max(n, 1), start=shard["row_lo"])
+    if n == 0:
+        data, offsets = data[:0], offsets[:1]
     d_data = torch.empty(len(data) + 64, dtype=torch.uint8, device=dev)
     d_data[: len(data)].copy_(torch.from_numpy(data))
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
@@ -155,7 +170,7 @@ def gpu_step_factory(gen_cfg, n, row_lo, num_chunks, dev, local_rank):
 
     def step():
         r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
-                               device=local_rank, stream=stream, kernel=KERNEL)
+                               device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"])
         info["output_bytes"] = r.output_bytes
         st = r.stats
         r.free()
@@ -183,12 +198,19 @@ def main(argv=None):
     rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc) = run(args, gpu_step_factory, "nccl")
     if rank != 0:
         return
-    r0 = per_rank[0]
-    b_in, b_out = r0["input_bytes"], r0["output_bytes"]
-    alg_bytes = b_in + 8 * n + b_out                       # B_in + 8 (u64 offset) + B_out per record
-    emit_ms = agg["emit_kernel_ms_max"]
+    # roofline of the dominant kernel, on the slowest rank's launch: SURVEY 8(d) B_in + 8 (u64 offset) + B_out per record
+    rs = max(per_rank, key=lambda r: r["emit_kernel_ms"])
+    r0 = rs
+    b_in, b_out = rs["input_bytes"], rs["output_bytes"]
+    alg_bytes = b_in + 8 * rs["records"] + b_out
+    emit_ms = rs["emit_kernel_ms"]
     achieved = alg_bytes / (emit_ms * 1e-3) / 1e9 if emit_ms > 0 else 0.0
     path_ms = r0["size_kernel_ms"] + r0["scan_kernel_ms"] + r0["emit_kernel_ms"]
+    strong = args.scaling == "strong"
+    per_gpu = [{"rank": i, "records": int(r["records"]), "records_per_s": r["records"] / (r["step_ms"] * 1e-3) if r["step_ms"] else 0.0,
+                "kernel_ms": {"k_size": r["size_kernel_ms"], "k_scan": r["scan_kernel_ms"], "k_emit": r["emit_kernel_ms"]},
+                "emit_alg_GBps": (r["input_bytes"] + 8 * r["records"] + r["output_bytes"]) / (r["emit_kernel_ms"] * 1e-3) / 1e9
+                if r["emit_kernel_ms"] > 0 else 0.0} for i, r in enumerate(per_rank)]
     emit_kernel = "rh_spec_emit" if getattr(run, "info", {}).get("specialized") else "rh_k_emit"
     out = {
         "metric": "Avro records/sec -> Arrow (direct decode, input and output resident in HBM)",
@@ -199,13 +221,18 @@ def main(argv=None):
         "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic (seeded generator with scripts/generate_avro.py's distributions; Faker unavailable)",
-        "config": {"workload": desc, "records_per_gpu": n, "num_chunks": num_chunks,
-                   "schema": gen_cfg, "input_bytes_per_gpu": int(b_in), "arrow_bytes_per_gpu": int(b_out),
-                   "parallelism": f"{world} x independent shard (no data-path collective)",
+        "config": {"workload": desc + (f", list-partitioned over {world} GPUs (BASELINE.json config 5 shape)" if strong and world > 1 else ""),
+                   "records_total": int(sum(r["records"] for r in per_rank)), "records_per_gpu": [int(r["records"]) for r in per_rank],
+                   "num_chunks": num_chunks, "schema": gen_cfg,
+                   "input_bytes_total": int(sum(r["input_bytes"] for r in per_rank)),
+                   "arrow_bytes_total": int(sum(r["output_bytes"] for r in per_rank)),
+                   "parallelism": (f"{world} GPUs x whole reference chunks of ONE list (rh_shard_chunks), no data-path collective" if strong
+                                   else f"{world} x independent 10M-record shard (weak), no data-path collective"),
+                   "per_gpu": per_gpu,
                    "kernel_ms": {"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
                    "kernel_form": "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter",
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
@@ -215,7 +242,7 @@ def main(argv=None):
                      "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": measured_traffic(emit_kernel) if args.workload == "full10m" else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "bytes_per_record": alg_bytes / n, "avg_launch_ms": emit_ms},
+                     "bytes_per_record": alg_bytes / max(rs["records"], 1), "avg_launch_ms": emit_ms},
     }
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n), num_chunks)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 2
+#define RH_ABI_VERSION 3
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -52,10 +52,34 @@ int rh_schema_export(const rh_schema* s, struct ArrowSchema* out);
  * of n records with `num_chunks` returns. */
 uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks);
 
+/* The multi-GPU deal (see rh_opts.devices): shard `shard` of `n_shards` owns chunks [*chunk_lo, *chunk_hi) of the
+ * k = rh_clamp_chunks(n, num_chunks) reference chunks, i.e. rows [*row_lo, *row_hi) (build_slices,
+ * deserialize.rs:57-68: k-1 chunks of n/k rows, the last one takes the remainder).  A shard may be empty (k < g). */
+void rh_shard_chunks(uint64_t n, uint64_t num_chunks, uint32_t n_shards, uint32_t shard,
+                     uint32_t* chunk_lo, uint32_t* chunk_hi, uint64_t* row_lo, uint64_t* row_hi);
+
+typedef struct rh_stats rh_stats;
+
+/* Call options.  Zero-initialise (memset / `rh_opts o = {0}`) and set `device = -1` for "current device"; fields
+ * after `stream` were added in ABI version 3 and are all "0 = off". */
 typedef struct {
   int32_t device;        /* HIP device ordinal; -1 = current device          */
   int32_t flags;         /* RH_KERNEL_* below; 0 = automatic                 */
   void* stream;          /* hipStream_t to launch on; NULL = engine's stream */
+  /* Multi-GPU form of the chunk driver (rh_decode / rh_decode_packed): the reference deals its k chunks to a thread
+   * pool (ruhvro/src/deserialize.rs:92-120); here the k chunks are dealt to `n_devices` shards in contiguous runs --
+   * shard j decodes chunks [j*k/g, (j+1)*k/g) on HIP device devices[j], with its own host thread, streams and arenas
+   * -- so every returned batch is produced entirely by one GPU and the result is identical for every g.  Ordinals may
+   * repeat (several logical shards on one GPU).  NULL / 0 = the single device named by `device`. */
+  const int32_t* devices;
+  uint32_t n_devices;
+  uint32_t reserved0;
+  /* Explicit chunk geometry for a caller that decodes a RANGE of a larger call's chunks (one process per GPU, each
+   * holding whole reference chunks): when non-zero, the n records are `num_chunks` chunks of `chunk_rows` rows, the
+   * last one taking the rest (deserialize.rs:57-68 applied to the whole list, not to this range).  0 = the
+   * reference's split of these n records (n / num_chunks). */
+  uint64_t chunk_rows;
+  rh_stats* device_stats; /* optional, room for n_devices entries: per-shard stage timings of a multi-GPU call */
 } rh_opts;
 
 /* Kernel selection (rh_opts.flags).  Both forms are HIP kernels running the same field handlers and
@@ -66,7 +90,7 @@ typedef struct {
 #define RH_KERNEL_GENERIC 1
 #define RH_KERNEL_SPECIALIZED 2
 
-typedef struct {
+struct rh_stats {
   uint64_t records;
   uint64_t input_bytes;      /* Avro payload bytes                               */
   uint64_t output_bytes;     /* Arrow buffer bytes produced (all chunks)         */
@@ -81,7 +105,7 @@ typedef struct {
   float total_ms;
   uint32_t specialized;      /* 1 = schema-specialised kernels ran, 0 = generic interpreter */
   uint32_t lds_bytes;        /* dynamic LDS per workgroup of the emit kernel                 */
-} rh_stats;
+};
 
 /* Replaces ruhvro::deserialize::per_datum_deserialize_threaded
  * (ruhvro/src/deserialize.rs:76-121; single-chunk form per_datum_deserialize,

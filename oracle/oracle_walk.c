@@ -148,7 +148,7 @@ static inline int union_branch(cur_t *c, int null_first, int *is_value, err_t *e
 }
 static inline int read_block_count(cur_t *c, int64_t *n, err_t *er) { /* 689-700 */
   if (read_zigzag_long(c, n, er)) return 1;
-  if (*n < 0) { int64_t sz; if (read_zigzag_long(c, &sz, er)) return 1; *n = -*n; }
+  if (*n < 0) { int64_t sz; if (read_zigzag_long(c, &sz, er)) return 1; *n = (int64_t)(0 - (uint64_t)*n); /* wrapping: i64::MIN stays negative -> `0..n` is empty */ }
   return 0;
 }
 

@@ -116,7 +116,9 @@ def read_block_count(c: _Cur) -> int:
     n = read_zigzag_long(c)
     if n < 0:
         read_zigzag_long(c)  # block byte size, ignored
-        return -n
+        # `n = -n` on an i64: i64::MIN negates to itself in the release build (wrapping), and `for _ in 0..n` over a
+        # negative n is empty -- the block carries no items and is NOT the terminator (the loop only stops at n == 0)
+        return n if n == -(1 << 63) else -n
     return n
 
 

@@ -6,7 +6,13 @@ as the reference's PyO3 module (``/src/lib.rs:56-158`` of Tyler-Sch/pyruhvro):
     deserialize_array(list, schema) -> pyarrow.RecordBatch
     deserialize_array_threaded(list, schema, num_chunks) -> list[pyarrow.RecordBatch]
     deserialize_array_threaded_spawn(list, schema, num_chunks) -> list[pyarrow.RecordBatch]
-    serialize_record_batch / serialize_record_batch_spawn  (other direction: not on this path yet)
+    serialize_record_batch(batch, schema, num_chunks) -> list[pyarrow.BinaryArray]   (Arrow -> Avro, also on the GPU)
+    serialize_record_batch_spawn(...)                                                 same
+
+Several GPUs: ``set_devices([0, 1, ...])`` (or ``PYRUHVRO_DEVICES=0,1,...`` in the environment) deals the
+``num_chunks`` output chunks to those devices in contiguous runs, so every returned batch is produced by one GPU and
+the result does not depend on how many there are (the reference deals its chunks to a thread pool the same way,
+``ruhvro/src/deserialize.rs:92-120``).
 
 The decode runs in hand-written HIP kernels on the GPU through the C ABI in
 ``include/ruhvro_hip.h`` (``libruhvro_hip.so``).  There is no CPU decode path in
@@ -95,6 +101,39 @@ def set_kernel_mode(mode) -> int:
     return old
 
 
+_devices = None      # None: the current HIP device; else the ordinals the chunks are dealt to
+
+
+def _env_devices():
+    e = os.environ.get("PYRUHVRO_DEVICES", "").strip()
+    if not e:
+        return None
+    try:
+        return [int(x) for x in e.split(",") if x.strip() != ""]
+    except ValueError:
+        raise ValueError(f"PYRUHVRO_DEVICES: expected comma-separated device ordinals, got {e!r}") from None
+
+
+def set_devices(devices):
+    """Deal the chunks of every later decode call to these HIP devices (a sequence of ordinals; an ordinal may repeat
+    to run several logical shards on one GPU; ``None`` = back to the current device / ``PYRUHVRO_DEVICES``).
+    Returns the previous setting."""
+    global _devices
+    old = _devices
+    if devices is None:
+        _devices = None
+    else:
+        devs = [int(d) for d in devices]
+        if not devs:
+            raise ValueError("set_devices: empty device list")
+        _devices = devs
+    return old
+
+
+def _current_devices():
+    return _devices if _devices is not None else _env_devices()
+
+
 def _decode(list_, schema: str, num_chunks: int, want_stats: bool = False, device: int = -1, stream: int = 0):
     comp = _get_schema(schema)
     nat = _require_native()
@@ -102,7 +141,8 @@ def _decode(list_, schema: str, num_chunks: int, want_stats: bool = False, devic
         raise TypeError("argument 'num_chunks': expected int")
     if num_chunks < 0:
         raise OverflowError("can't convert negative int to unsigned")  # usize extraction in PyO3
-    addrs, stats = nat.decode(comp.capsule, list_, num_chunks, device, stream, want_stats, _kernel_mode)
+    devs = _current_devices() if device < 0 and not stream else None
+    addrs, stats = nat.decode(comp.capsule, list_, num_chunks, device, stream, want_stats, _kernel_mode, devs)
     out: List[pa.RecordBatch] = []
     try:
         for i, a in enumerate(addrs):
@@ -164,7 +204,7 @@ def deserialize_binary_array(array, schema, num_chunks):
     data = (np.frombuffer(bufs[2], dtype=np.uint8, count=end)[base:] if bufs[2] is not None and end > base
             else np.zeros(1, dtype=np.uint8))
     offsets = (offs.astype(np.uint64) - np.uint64(base)) if n else np.zeros(1, dtype=np.uint64)
-    return cabi.decode_packed(data, offsets, schema, num_chunks, kernel=_kernel_mode)
+    return cabi.decode_packed(data, offsets, schema, num_chunks, kernel=_kernel_mode, devices=_current_devices())
 
 
 def _encode(data, schema: str, num_chunks: int, want_stats: bool = False, device: int = -1, stream: int = 0):
@@ -224,5 +264,5 @@ __all__ = [
     "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
     "serialize_record_batch_with_stats",
     "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count", "set_kernel_mode",
-    "deserialize_binary_array",
+    "deserialize_binary_array", "set_devices",
 ]

@@ -19,10 +19,6 @@ LIB_PATH = os.path.join(_HERE, "libruhvro_hip.so")
 RH_OK, RH_ERR_SCHEMA, RH_ERR_DECODE, RH_ERR_RUNTIME, RH_ERR_ARGUMENT = range(5)
 
 
-class RhOpts(C.Structure):
-    _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p)]
-
-
 class RhStats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("input_bytes", C.c_uint64), ("output_bytes", C.c_uint64),
                 ("chunks", C.c_uint32), ("blocks", C.c_uint32), ("pack_ms", C.c_float), ("h2d_ms", C.c_float),
@@ -31,6 +27,30 @@ class RhStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RhOpts(C.Structure):
+    """rh_opts (ABI version 3).  Build with make_opts()."""
+    _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("reserved0", C.c_uint32),
+                ("chunk_rows", C.c_uint64), ("device_stats", C.POINTER(RhStats))]
+
+
+def make_opts(device: int = -1, kernel: int = 0, stream=None, devices=None, chunk_rows: int = 0):
+    """-> (RhOpts, keepalive).  `devices`: sequence of HIP ordinals to shard the chunks over (repeats allowed);
+    per-shard stats land in keepalive["device_stats"]."""
+    o = RhOpts()
+    o.device, o.flags, o.stream = device, kernel, stream or None
+    o.chunk_rows = chunk_rows
+    keep = {}
+    if devices:
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        st = (RhStats * len(devices))()
+        o.devices = C.cast(arr, C.POINTER(C.c_int32))
+        o.n_devices = len(devices)
+        o.device_stats = C.cast(st, C.POINTER(RhStats))
+        keep["devices"], keep["device_stats"] = arr, st
+    return o, keep
 
 
 class ArrowArray(C.Structure):
@@ -71,6 +91,9 @@ def lib():
         L.rh_schema_export.argtypes = [C.c_void_p, C.POINTER(ArrowSchema)]
         L.rh_clamp_chunks.restype = C.c_uint32
         L.rh_clamp_chunks.argtypes = [C.c_uint64, C.c_uint64]
+        L.rh_shard_chunks.restype = None
+        L.rh_shard_chunks.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.rh_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(RhOpts),
                                 C.POINTER(ArrowArray), C.POINTER(C.c_uint32), C.POINTER(RhStats), C.POINTER(C.c_char_p)]
         L.rh_decode_packed.argtypes = L.rh_decode.argtypes
@@ -179,9 +202,18 @@ def prebuild(schema_json: str) -> bool:
     return bool(cached.value)
 
 
+def shard_chunks(n: int, num_chunks: int, n_shards: int, shard: int):
+    """rh_shard_chunks -> (chunk_lo, chunk_hi, row_lo, row_hi): the multi-GPU deal of whole reference chunks."""
+    c0, c1, r0, r1 = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+    lib().rh_shard_chunks(n, num_chunks, n_shards, shard, C.byref(c0), C.byref(c1), C.byref(r0), C.byref(r1))
+    return c0.value, c1.value, r0.value, r1.value
+
+
 def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_chunks: int,
-                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO):
-    """rh_decode_packed: one contiguous payload + u64 offsets (host memory) -> list[RecordBatch]."""
+                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO, devices=None):
+    """rh_decode_packed: one contiguous payload + u64 offsets (host memory) -> list[RecordBatch].
+    `devices`: shard the chunks over these HIP devices (rh_opts.devices); with want_stats the stats dict then carries
+    the per-shard stats under "device_stats"."""
     L = lib()
     s = Schema.get(schema_json)
     data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -192,17 +224,22 @@ def decode_packed(data: np.ndarray, offsets: np.ndarray, schema_json: str, num_c
     out_k = C.c_uint32()
     st = RhStats()
     err = C.c_char_p()
-    opts = RhOpts(device, kernel, None)
+    opts, keep = make_opts(device, kernel, None, devices)
     rc = L.rh_decode_packed(s.handle, data.ctypes.data, offsets.ctypes.data, n, num_chunks, C.byref(opts), arr,
                             C.byref(out_k), C.byref(st), C.byref(err))
     if rc != RH_OK:
         _raise(rc, err)
     out = _import_chunks(arr, out_k.value, s.arrow_schema)
-    return (out, st.as_dict()) if want_stats else out
+    if not want_stats:
+        return out
+    d = st.as_dict()
+    if devices:
+        d["device_stats"] = [x.as_dict() for x in keep["device_stats"]]
+    return out, d
 
 
 def decode_slices(ptrs: np.ndarray, lens: np.ndarray, schema_json: str, num_chunks: int,
-                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO):
+                  device: int = -1, want_stats: bool = False, kernel: int = KERNEL_AUTO, devices=None):
     """rh_decode: one (pointer, length) pair per record, the form the CPython boundary extracts from list[bytes]
     (u64 addresses / u64 lengths; the caller keeps the pointed-to memory alive) -> list[RecordBatch]."""
     L = lib()
@@ -215,7 +252,7 @@ def decode_slices(ptrs: np.ndarray, lens: np.ndarray, schema_json: str, num_chun
     out_k = C.c_uint32()
     st = RhStats()
     err = C.c_char_p()
-    opts = RhOpts(device, kernel, None)
+    opts, keep = make_opts(device, kernel, None, devices)
     rc = L.rh_decode(s.handle, ptrs.ctypes.data, lens.ctypes.data, n, num_chunks, C.byref(opts), arr,
                      C.byref(out_k), C.byref(st), C.byref(err))
     if rc != RH_OK:
@@ -262,14 +299,16 @@ class DeviceResult:
 
 
 def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
-                  device: int = -1, stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO) -> DeviceResult:
-    """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr())."""
+                  device: int = -1, stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO,
+                  chunk_rows: int = 0) -> DeviceResult:
+    """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr()).  chunk_rows: explicit geometry
+    for a range of a larger call's chunks (rh_opts.chunk_rows)."""
     L = lib()
     s = Schema.get(schema_json)
     out = C.c_void_p()
     st = RhStats()
     err = C.c_char_p()
-    opts = RhOpts(device, kernel, stream or None)
+    opts, _keep = make_opts(device, kernel, stream, None, chunk_rows)
     rc = L.rh_decode_device(s.handle, d_data, d_offsets, data_len, n, num_chunks, C.byref(opts), C.byref(out),
                             C.byref(st) if want_stats else None, C.byref(err))
     if rc != RH_OK:

@@ -87,7 +87,12 @@ struct Block {
 
 class Pool {
  public:
-  explicit Pool(bool host) : host_(host) {}
+  explicit Pool(bool host) : host_(host) {
+    // cached (idle) bytes this pool may hold on to between calls.  Pinned host memory is the scarcer resource: a
+    // long-lived process should not keep tens of GiB page-locked because of one large call.
+    const char* e = std::getenv(host ? "RUHVRO_HIP_PINNED_CACHE_MB" : "RUHVRO_HIP_DEVICE_CACHE_MB");
+    max_cached_ = e ? ((uint64_t)std::strtoull(e, nullptr, 10) << 20) : (host ? (4ull << 30) : (24ull << 30));
+  }
   Block get(uint64_t size, int device) {
     size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
     {
@@ -137,7 +142,7 @@ class Pool {
       free_.push_back(b);
       cached_ += b.size;
     }
-    trim(kMaxCached);
+    trim(max_cached_);
   }
   void trim(uint64_t keep) {
     std::vector<Block> drop;
@@ -159,7 +164,7 @@ class Pool {
   }
 
  private:
-  static constexpr uint64_t kMaxCached = 24ull << 30;
+  uint64_t max_cached_;
   bool host_;
   std::mutex mu_;
   std::vector<Block> free_;
@@ -303,6 +308,13 @@ std::string format_error(const rh::ErrInfo& e) {
     case rh::E_INTERNAL: return "internal error: the fast and the careful walk disagree on a record";
     default: return "decode error";
   }
+}
+
+rh_opts default_opts() {
+  rh_opts o;
+  std::memset(&o, 0, sizeof o);
+  o.device = -1;
+  return o;
 }
 
 struct Timer {
@@ -528,9 +540,8 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   try {
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats, geo);
   } catch (const NeedWideIndex&) {
-    rh_opts o;
+    rh_opts o = default_opts();
     if (opts) o = *opts;
-    else { o.device = -1; o.stream = nullptr; }
     o.flags = RH_KERNEL_GENERIC;
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats, geo);
   }
@@ -545,14 +556,32 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
   if ((uintptr_t)d_data & 15) throw std::invalid_argument("device payload pointer must be 16-byte aligned");
 
-  static std::once_flag lds_once;
-  std::call_once(lds_once, [] { (void)rh_set_max_lds(160 * 1024); });
+  {   // the generic kernels' dynamic-LDS limit is a per-device function attribute: set it once per device
+    static std::mutex lds_mu;
+    static std::vector<int> lds_done;
+    std::lock_guard<std::mutex> g(lds_mu);
+    if (std::find(lds_done.begin(), lds_done.end(), device) == lds_done.end()) {
+      if (rh_set_max_lds(160 * 1024) != 0) throw HipError("cannot raise the dynamic LDS limit of the decode kernels");
+      lds_done.push_back(device);
+    }
+  }
 
   auto res = std::make_unique<rh_device_result>();
   rh_device_result& r = *res;
   r.cs = &cs;
   r.device = device;
   r.n = n;
+  ChunkGeo ogeo;
+  if (!geo && opts && opts->chunk_rows) {   // a range of a larger call's chunks (one process per GPU): rh_opts.chunk_rows
+    if (num_chunks < 1 || num_chunks > 0xFFFFFFFFull || (num_chunks - 1) > n / opts->chunk_rows ||
+        (n > 0 && n == (num_chunks - 1) * opts->chunk_rows && num_chunks > 1))
+      throw std::invalid_argument("chunk_rows: the n records do not make num_chunks chunks of chunk_rows rows (the last one takes the rest)");
+    ogeo.k = (uint32_t)num_chunks;
+    ogeo.sz = opts->chunk_rows;
+    ogeo.rows_last = n - (num_chunks - 1) * opts->chunk_rows;
+    ogeo.payload_bytes = data_len;
+    geo = &ogeo;
+  }
   const uint32_t k = geo ? geo->k : rh_clamp_chunks(n, num_chunks);
   r.k = k;
   r.sz = geo ? geo->sz : n / k;
@@ -793,7 +822,15 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStrea
 int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream = nullptr) {
   Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
   slab->refs.store(1);   // guard while building
-  for (uint32_t c = 0; c < r->k; c++) export_chunk(*r, c, (const uint8_t*)slab->base, slab, &out_chunks[c]);
+  uint32_t built = 0;
+  try {
+    for (; built < r->k; built++) export_chunk(*r, built, (const uint8_t*)slab->base, slab, &out_chunks[built]);
+  } catch (...) {          // drop the chunks already exported (each holds a slab reference), then the guard
+    for (uint32_t c = 0; c < built; c++)
+      if (out_chunks[c].release) out_chunks[c].release(&out_chunks[c]);
+    if (slab->refs.fetch_sub(1) == 1) { slab->free_mem(); delete slab; }
+    throw;
+  }
   if (slab->refs.fetch_sub(1) == 1) { slab->free_mem(); delete slab; }
   return 0;
 }
@@ -869,7 +906,7 @@ void decode_packed_range(rh_schema* s, const uint8_t* data, const uint64_t* offs
   const uint64_t lead = 16 + (lo & 15);
   const uint64_t o_off = align_up(lead + (hi - lo) + 32, kAlign);
   Lease din(dev_pool(), o_off + 8 * (n + 1), device);
-  rh_opts o;
+  rh_opts o = default_opts();
   o.device = device;
   o.flags = opts ? opts->flags : 0;
   o.stream = (void*)stream;
@@ -910,77 +947,145 @@ uint64_t pipeline_min_bytes(bool source_pinned) {      // read per call: tests s
   return source_pinned ? (256ull << 20) : ~0ull;
 }
 
+// One contiguous run of a call's chunks, decoded by one host thread on one device with its own stream and arenas.
+struct Shard {
+  uint32_t c0 = 0, c1 = 0;      // chunks [c0, c1) of the call
+  int device = 0;
+  uint32_t gate = 0;            // index of the turnstile pair of its device
+  uint32_t ticket = 0;          // order among the shards of that device
+};
+
 int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
                        const rh_opts* opts, ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, float pack_ms,
                        bool source_pinned) {
   require_device();
   Timer total;
-  int device = 0;
-  if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
-  else HIPCHK(hipGetDevice(&device));
-  hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
   const uint32_t k = rh_clamp_chunks(n, num_chunks);
+  std::memset(out_chunks, 0, sizeof(ArrowArray) * k);      // the failure paths release whatever was produced
+  if (opts && opts->chunk_rows) throw std::invalid_argument("chunk_rows applies to rh_decode_device only");
+  const bool multi = opts && opts->n_devices > 0;
+  if (multi && !opts->devices) throw std::invalid_argument("n_devices > 0 with a NULL device list");
+  int device = 0;
+  if (!multi) {
+    if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
+    else HIPCHK(hipGetDevice(&device));
+  }
+  hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
+  if (multi && user_stream) throw std::invalid_argument("a multi-device call runs on the engine's own streams (stream must be NULL)");
   const uint64_t bytes = n ? offsets[n] - offsets[0] : 0;
 
-  // Large calls on the default stream are pipelined: chunks are independent (deserialize.rs:92-120), so contiguous
-  // groups of chunks go through H2D -> kernels -> D2H on their own streams, staggered so that the link carries one
-  // group's results out while the next group's records come in.
-  const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned)) ? std::min<uint32_t>(k, 8) : 1;
-  if (groups <= 1) {
-    decode_packed_range(s, data, offsets, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats,
-                        nullptr, nullptr, 0);
-    if (stats) {
-      stats->pack_ms = pack_ms;
-      stats->total_ms = total.ms() + pack_ms;
+  // ---- the deal: which chunks go where
+  std::vector<Shard> shards;
+  std::vector<int> gate_device;          // one turnstile pair per distinct device
+  if (multi) {
+    // SURVEY 8(e) / rh_opts.devices: shard j of g gets chunks [j*k/g, (j+1)*k/g) on devices[j].  The shards of ONE device
+    // share its PCIe link, so they pass its two copy directions in order (as the pipelined groups below do); shards of
+    // different devices never wait for each other.
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    for (uint32_t j = 0; j < opts->n_devices; j++) {
+      const int d = opts->devices[j];
+      if (d < 0 || d >= ndev) throw std::invalid_argument("device ordinal " + std::to_string(d) + " out of range (" + std::to_string(ndev) + " visible)");
+      Shard sh;
+      sh.device = d;
+      rh_shard_chunks(n, num_chunks, opts->n_devices, j, &sh.c0, &sh.c1, nullptr, nullptr);
+      size_t gi = std::find(gate_device.begin(), gate_device.end(), d) - gate_device.begin();
+      if (gi == gate_device.size()) gate_device.push_back(d);
+      sh.gate = (uint32_t)gi;
+      shards.push_back(sh);
     }
-    return RH_OK;
+    std::vector<uint32_t> next_ticket(gate_device.size(), 0);
+    for (Shard& sh : shards) sh.ticket = next_ticket[sh.gate]++;
+  } else {
+    // Large calls on the default stream are pipelined: chunks are independent (deserialize.rs:92-120), so contiguous
+    // groups of chunks go through H2D -> kernels -> D2H on their own streams, staggered so that the link carries one
+    // group's results out while the next group's records come in.
+    const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned)) ? std::min<uint32_t>(k, 8) : 1;
+    if (groups <= 1) {
+      decode_packed_range(s, data, offsets, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats,
+                          nullptr, nullptr, 0);
+      if (stats) {
+        stats->pack_ms = pack_ms;
+        stats->total_ms = total.ms() + pack_ms;
+      }
+      return RH_OK;
+    }
+    gate_device.push_back(device);
+    for (uint32_t g = 0; g < groups; g++) {
+      Shard sh;
+      sh.device = device;
+      sh.c0 = (uint32_t)((uint64_t)k * g / groups);
+      sh.c1 = (uint32_t)((uint64_t)k * (g + 1) / groups);
+      sh.ticket = g;
+      shards.push_back(sh);
+    }
   }
 
   const uint64_t sz = n / k, rows_last = n - (uint64_t)(k - 1) * sz;
-  std::vector<rh_stats> gstats(groups);
-  std::vector<std::exception_ptr> failed(groups);
-  Turnstile h2d_gate, d2h_gate;
+  const size_t ns = shards.size();
+  std::vector<rh_stats> gstats(ns);
+  for (auto& gs : gstats) std::memset(&gs, 0, sizeof gs);
+  std::vector<std::exception_ptr> failed(ns);
+  std::vector<Turnstile> h2d_gates(gate_device.size()), d2h_gates(gate_device.size());
+  const bool want = stats || (multi && opts->device_stats);
+  rh_opts sopts = default_opts();
+  sopts.flags = opts ? opts->flags : 0;
   std::vector<std::thread> th;
-  for (uint32_t g = 0; g < groups; g++) {
+  for (size_t g = 0; g < ns; g++) {
     th.emplace_back([&, g] {
+      const Shard& sh = shards[g];
       hipStream_t st = nullptr;
       try {
-        HIPCHK(hipSetDevice(device));
-        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        const uint32_t c0 = (uint32_t)((uint64_t)k * g / groups), c1 = (uint32_t)((uint64_t)k * (g + 1) / groups);
-        const uint64_t r0 = (uint64_t)c0 * sz, r1 = c1 == k ? n : (uint64_t)c1 * sz;
-        ChunkGeo geo;
-        geo.k = c1 - c0;
-        geo.sz = sz;
-        geo.rows_last = c1 == k ? rows_last : sz;
-        geo.payload_bytes = offsets[r1] - offsets[r0];
-        std::memset(&gstats[g], 0, sizeof(rh_stats));
-        decode_packed_range(s, data, offsets + r0, r1 - r0, 0, &geo, opts, device, st, out_chunks + c0, nullptr,
-                            stats ? &gstats[g] : nullptr, &h2d_gate, &d2h_gate, g);
+        if (sh.c1 > sh.c0) {             // an empty shard (k < g) only passes its gates
+          HIPCHK(hipSetDevice(sh.device));
+          HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+          const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
+          ChunkGeo geo;
+          geo.k = sh.c1 - sh.c0;
+          geo.sz = sz;
+          geo.rows_last = sh.c1 == k ? rows_last : sz;
+          geo.payload_bytes = offsets[r1] - offsets[r0];
+          Timer tsh;
+          decode_packed_range(s, data, offsets + r0, r1 - r0, 0, &geo, &sopts, sh.device, st, out_chunks + sh.c0, nullptr,
+                              want ? &gstats[g] : nullptr, &h2d_gates[sh.gate], &d2h_gates[sh.gate], sh.ticket);
+          gstats[g].total_ms = tsh.ms();
+        }
       } catch (...) {
         failed[g] = std::current_exception();
       }
-      h2d_gate.finish(g);
-      d2h_gate.finish(g);
+      h2d_gates[sh.gate].finish(sh.ticket);
+      d2h_gates[sh.gate].finish(sh.ticket);
       if (st) (void)hipStreamDestroy(st);
     });
   }
   for (auto& t : th) t.join();
-  for (uint32_t g = 0; g < groups; g++) {
+  for (size_t g = 0; g < ns; g++) {
     if (!failed[g]) continue;
-    for (uint32_t c = 0; c < k; c++)        // the call fails as a whole: drop what the other groups produced
+    for (uint32_t c = 0; c < k; c++)        // the call fails as a whole: drop what the other shards produced
       if (out_chunks[c].release) out_chunks[c].release(&out_chunks[c]);
-    std::rethrow_exception(failed[g]);      // lowest group = lowest rows: the error the serial order meets first
+    std::rethrow_exception(failed[g]);      // lowest shard = lowest rows: the error the serial order meets first
   }
   if (out_k) *out_k = k;
+  if (multi && opts->device_stats)
+    for (size_t g = 0; g < ns; g++) opts->device_stats[g] = gstats[g];
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    for (const rh_stats& gs : gstats) {     // stage times are sums over the groups (they overlap in wall time)
+    // stage times: shards of one device run one after the other through each stage (sum); devices run side by side (max)
+    std::vector<rh_stats> per_dev(gate_device.size());
+    for (auto& d : per_dev) std::memset(&d, 0, sizeof d);
+    for (size_t g = 0; g < ns; g++) {
+      const rh_stats& gs = gstats[g];
       stats->records += gs.records; stats->input_bytes += gs.input_bytes; stats->output_bytes += gs.output_bytes;
       stats->blocks += gs.blocks;
-      stats->h2d_ms += gs.h2d_ms; stats->size_kernel_ms += gs.size_kernel_ms; stats->scan_kernel_ms += gs.scan_kernel_ms;
-      stats->emit_kernel_ms += gs.emit_kernel_ms; stats->d2h_ms += gs.d2h_ms;
-      stats->specialized = gs.specialized; stats->lds_bytes = gs.lds_bytes;
+      rh_stats& d = per_dev[shards[g].gate];
+      d.h2d_ms += gs.h2d_ms; d.size_kernel_ms += gs.size_kernel_ms; d.scan_kernel_ms += gs.scan_kernel_ms;
+      d.emit_kernel_ms += gs.emit_kernel_ms; d.d2h_ms += gs.d2h_ms;
+      if (gs.records) { stats->specialized = gs.specialized; stats->lds_bytes = gs.lds_bytes; }
+    }
+    for (const rh_stats& d : per_dev) {
+      stats->h2d_ms = std::max(stats->h2d_ms, d.h2d_ms); stats->size_kernel_ms = std::max(stats->size_kernel_ms, d.size_kernel_ms);
+      stats->scan_kernel_ms = std::max(stats->scan_kernel_ms, d.scan_kernel_ms);
+      stats->emit_kernel_ms = std::max(stats->emit_kernel_ms, d.emit_kernel_ms); stats->d2h_ms = std::max(stats->d2h_ms, d.d2h_ms);
     }
     stats->chunks = k;
     stats->pack_ms = pack_ms;
@@ -1010,6 +1115,18 @@ uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks) {   // deserialize.rs:
   uint64_t k = std::max<uint64_t>(num_chunks, 1);
   k = std::min<uint64_t>(k, std::max<uint64_t>(n, 1));
   return (uint32_t)std::min<uint64_t>(k, 0xFFFFFFFFull);
+}
+
+void rh_shard_chunks(uint64_t n, uint64_t num_chunks, uint32_t n_shards, uint32_t shard, uint32_t* chunk_lo,
+                     uint32_t* chunk_hi, uint64_t* row_lo, uint64_t* row_hi) {
+  const uint64_t k = rh_clamp_chunks(n, num_chunks);
+  const uint64_t g = std::max<uint32_t>(n_shards, 1), j = std::min<uint64_t>(shard, g - 1);
+  const uint64_t c0 = k * j / g, c1 = k * (j + 1) / g;
+  const uint64_t sz = n / k;
+  if (chunk_lo) *chunk_lo = (uint32_t)c0;
+  if (chunk_hi) *chunk_hi = (uint32_t)c1;
+  if (row_lo) *row_lo = c0 * sz;
+  if (row_hi) *row_hi = c1 == k ? n : c1 * sz;
 }
 
 rh_schema* rh_schema_compile(const char* json, size_t len, char** err) {

@@ -90,7 +90,8 @@ PyObject* stats_dict(const rh_stats& st) {
                        "total_ms", st.total_ms, "specialized", st.specialized, "lds_bytes", st.lds_bytes);
 }
 
-// decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)
+// decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0, devices=None)
+//   devices: None, or a sequence of HIP device ordinals to shard the chunks over (rh_opts.devices)
 //   -> (list[int] addresses of malloc'd ArrowArray structs, stats dict | None)
 PyObject* py_decode(PyObject*, PyObject* args) {
   PyObject *cap, *list;
@@ -99,9 +100,21 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   unsigned long long stream = 0;
   int want_stats = 0;
   int kernel = RH_KERNEL_AUTO;
-  if (!PyArg_ParseTuple(args, "OOK|iKpi", &cap, &list, &num_chunks, &device, &stream, &want_stats, &kernel)) return nullptr;
+  PyObject* devs = Py_None;
+  if (!PyArg_ParseTuple(args, "OOK|iKpiO", &cap, &list, &num_chunks, &device, &stream, &want_stats, &kernel, &devs)) return nullptr;
   rh_schema* s = get_schema(cap);
   if (!s) return nullptr;
+  std::vector<int32_t> devices;
+  if (devs != Py_None) {
+    PyObject* seq = PySequence_Fast(devs, "argument 'devices': expected a sequence of ints");
+    if (!seq) return nullptr;
+    for (Py_ssize_t i = 0; i < PySequence_Fast_GET_SIZE(seq); i++) {
+      const long d = PyLong_AsLong(PySequence_Fast_GET_ITEM(seq, i));
+      if (d == -1 && PyErr_Occurred()) { Py_DECREF(seq); return nullptr; }
+      devices.push_back((int32_t)d);
+    }
+    Py_DECREF(seq);
+  }
   if (!PyList_Check(list)) {
     PyErr_SetString(PyExc_TypeError, "argument 'list': expected a list of bytes");
     return nullptr;
@@ -135,9 +148,11 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   const uint32_t k = rh_clamp_chunks((uint64_t)n, num_chunks);
   ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
   rh_opts opts;
+  std::memset(&opts, 0, sizeof opts);
   opts.device = device;
   opts.flags = kernel;
   opts.stream = (void*)(uintptr_t)stream;
+  if (!devices.empty()) { opts.devices = devices.data(); opts.n_devices = (uint32_t)devices.size(); }
   rh_stats st;
   std::memset(&st, 0, sizeof st);
   char* err = nullptr;
@@ -193,6 +208,7 @@ PyObject* py_encode(PyObject*, PyObject* args) {
   const uint32_t k = rh_clamp_chunks((uint64_t)arr->length, num_chunks);
   ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
   rh_opts opts;
+  std::memset(&opts, 0, sizeof opts);
   opts.device = device;
   opts.flags = kernel;
   opts.stream = (void*)(uintptr_t)stream;
@@ -242,7 +258,7 @@ PyMethodDef methods[] = {
     {"compile_schema", py_compile_schema, METH_VARARGS, "compile_schema(json) -> schema capsule"},
     {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
     {"export_schema", py_export_schema, METH_VARARGS, "export_schema(capsule) -> address of ArrowSchema"},
-    {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
+    {"decode", py_decode, METH_VARARGS, "decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0, devices=None)"},
     {"encode", py_encode, METH_VARARGS, "encode(capsule, array_addr, schema_addr, num_chunks, device=-1, stream=0, want_stats=False, kernel=0)"},
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},

@@ -18,6 +18,18 @@ def shard_rows(n_per_rank: int, rank: int) -> Tuple[int, int]:
     return rank * n_per_rank, (rank + 1) * n_per_rank
 
 
+def strong_shard(n: int, num_chunks: int, world: int, rank: int) -> Dict[str, int]:
+    """One list of n records over `world` GPUs, one process per GPU (BASELINE config 5): this rank's rows and the
+    chunk geometry to hand rh_decode_device (rh_opts.chunk_rows) so that its batches are exactly the reference's
+    chunks [c0, c1) of the WHOLE list (rh_shard_chunks in the C ABI -- the same deal rh_decode makes for a device
+    list inside one process)."""
+    from . import cabi
+    c0, c1, r0, r1 = cabi.shard_chunks(n, num_chunks, world, rank)
+    k = max(1, min(max(num_chunks, 1), max(n, 1)))
+    return {"row_lo": r0, "rows": r1 - r0, "chunks": c1 - c0, "chunk_rows": n // k if c1 > c0 else 0,
+            "chunk_lo": c0, "chunk_hi": c1}
+
+
 def partition_chunks(n: int, num_chunks: int, world: int) -> List[List[Tuple[int, int]]]:
     """Strong-scaling form (one list over `world` GPUs): chunk boundaries of the reference
     (deserialize.rs:53-68) are kept, whole chunks are dealt to GPUs in contiguous runs, so every

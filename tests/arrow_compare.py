@@ -11,17 +11,37 @@ import numpy as np
 import pyarrow as pa
 
 
+class _View:
+    """The first n bytes of an Arrow buffer as a zero-copy numpy view; == compares contents (vectorised, so the
+    10M-record configuration gets the same bar as the small ones)."""
+
+    def __init__(self, buf, n):
+        if n == 0:
+            self.a = np.zeros(0, dtype=np.uint8)
+            return
+        assert buf is not None, "missing buffer"
+        assert buf.size >= n, f"buffer too small: {buf.size} < {n}"
+        self.a = np.frombuffer(buf, dtype=np.uint8, count=n)
+
+    def __eq__(self, other):
+        return self.a.shape == other.a.shape and bool(np.array_equal(self.a, other.a))
+
+    def i32(self):
+        return self.a.view(np.int32)
+
+
 def _bytes(buf, n):
-    if n == 0:
-        return b""
-    assert buf is not None, "missing buffer"
-    assert buf.size >= n, f"buffer too small: {buf.size} < {n}"
-    return buf.to_pybytes()[:n]
+    return _View(buf, n)
 
 
 def _bits(buf, nbits):
-    raw = np.frombuffer(_bytes(buf, (nbits + 7) // 8), dtype=np.uint8)
-    return np.unpackbits(raw, bitorder="little")[:nbits]
+    """Validity / boolean bitmap restricted to its nbits meaningful bits, as bytes with the padding bits masked."""
+    nb = (nbits + 7) // 8
+    raw = _View(buf, nb).a
+    if nbits & 7 and nb:
+        raw = raw.copy()
+        raw[-1] &= (1 << (nbits & 7)) - 1
+    return raw
 
 
 def assert_identical(a: pa.Array, b: pa.Array, path: str = "") -> None:
@@ -42,7 +62,7 @@ def assert_identical(a: pa.Array, b: pa.Array, path: str = "") -> None:
         assert np.array_equal(_bits(ba[1], n), _bits(bb[1], n)), f"{path}: boolean values differ"
     elif pa.types.is_string(t):
         assert _bytes(ba[1], 4 * (n + 1)) == _bytes(bb[1], 4 * (n + 1)), f"{path}: string offsets differ"
-        last = int(np.frombuffer(_bytes(ba[1], 4 * (n + 1)), dtype=np.int32)[-1])
+        last = int(_bytes(ba[1], 4 * (n + 1)).i32()[-1])
         assert _bytes(ba[2], last) == _bytes(bb[2], last), f"{path}: string data differ"
     elif pa.types.is_struct(t):
         for i in range(t.num_fields):

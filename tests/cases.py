@@ -84,6 +84,15 @@ def wire_cases():
         to_datum(sa, {"tags": ["solo"]}) + b"\xde\xad\xbe\xef",            # trailing bytes are ignored (fast_decode.rs:825-828)
     ]
     out.append(("array_blocks", s_arr, recs))
+    # a block count of i64::MIN: `-n` wraps to itself (release build), `0..n` is empty, and it is not the terminator --
+    # an EMPTY block with a byte size, after which the array goes on (fast_decode.rs:689-700, 703-719)
+    i64min = zigzag(-(1 << 63))
+    recs = [
+        i64min + zigzag(5) + zigzag(2) + zigzag(1) + b"p" + zigzag(1) + b"q" + zigzag(0),
+        zigzag(1) + zigzag(2) + b"ab" + i64min + zigzag(0) + i64min + zigzag(123456) + zigzag(0),
+        to_datum(sa, {"tags": ["plain"]}),
+    ]
+    out.append(("array_block_count_i64_min", s_arr, recs))
     s_map = SCHEMAS["t_map_str"]
     sm = parse_schema(s_map)
     recs = [
