@@ -16,12 +16,16 @@ N > 1 (BASELINE.json config 5): the SAME seeded 10M-record list, its 8 reference
 collective: records are independent; RCCL carries the barrier, the MAX over rank times and the stats all-gather.
 `--scaling weak` keeps round 1's mode (every rank decodes its own 10M records of the stream).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with three extra objects:
   roofline      k_emit (the dominant kernel): algorithmic bytes per launch / its mean launch duration,
                 measured with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM.
   cpu_baseline  the oracle's C restatement of the reference walker ("port"), reference threading shape
                 (serial pack + one thread per chunk, 8 chunks), timed on this box's host cores on a
                 bounded sample of the same workload.  Reported, not targeted.
+  end_to_end    (N=1 only) the same workload through the HOST entry points of the C ABI -- host records in, host
+                Arrow batches out, PCIe both ways included -- so the CPU baseline has a like-for-like neighbour:
+                rh_decode_packed (one packed payload), rh_decode (one slice per record, what the CPython boundary
+                extracts from list[bytes]) and the Python surface itself on a bounded sample.  Never `value`.
 """
 from __future__ import annotations
 
@@ -53,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="full10m", choices=sorted(WORKLOADS))
     ap.add_argument("--records", type=int, default=0, help="override records per GPU (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -88,6 +93,51 @@ def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int)
         "sample": f"{n_sample} records of the same workload, {num_chunks} chunks = {num_chunks} threads "
                   f"(reference shape: serial pack + one task per chunk), best of 3; host has {os.cpu_count()} cpus",
     }
+
+
+def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sample: int = 2_000_000):
+    """Host in -> host out through the C ABI's host entry points (PCIe-inclusive), best of 3 each, with the engine's
+    stage timings (rh_stats).  The payload is generated once; slices point into it."""
+    import numpy as np
+    import pyruhvro_amd as P
+    from avrogen import fastgen
+    from pyruhvro_amd import cabi
+
+    data, offsets = fastgen.generate(gen_cfg, n)
+    out = {"records": n, "input_bytes": int(offsets[-1]), "num_chunks": num_chunks, "unit": "records/s"}
+
+    def best_of(f, reps=3):
+        best = None
+        for _ in range(reps):
+            t = time.perf_counter()
+            res, st = f()
+            wall = time.perf_counter() - t
+            del res
+            if best is None or wall < best[0]:
+                best = (wall, st)
+        wall, st = best
+        keys = ("pack_ms", "h2d_ms", "size_kernel_ms", "scan_kernel_ms", "emit_kernel_ms", "d2h_ms", "total_ms")
+        return {"value": n / wall, "wall_ms": wall * 1e3, "stage_ms": {k: round(float(st[k]), 3) for k in keys}}
+
+    out["packed_pageable"] = best_of(lambda: cabi.decode_packed(data, offsets, schema_json, num_chunks, want_stats=True))
+    out["packed_pageable"]["what"] = "rh_decode_packed: one pageable payload + u64 offsets -> host RecordBatches"
+    ptrs = (np.uint64(data.ctypes.data) + offsets[:-1]).astype(np.uint64)
+    lens = np.diff(offsets).astype(np.uint64)
+    out["record_slices"] = best_of(lambda: cabi.decode_slices(ptrs, lens, schema_json, num_chunks, want_stats=True))
+    out["record_slices"]["what"] = ("rh_decode: one (pointer, length) per record, gathered into pinned memory per chunk group "
+                                    "while earlier groups are on the wire -> host RecordBatches")
+    m = min(py_sample, n)
+    recs = fastgen.split(data[: int(offsets[m])], offsets[: m + 1])
+    P.deserialize_array_threaded(recs, schema_json, num_chunks)
+    best = float("inf")
+    for _ in range(2):
+        t = time.perf_counter()
+        res = P.deserialize_array_threaded(recs, schema_json, num_chunks)
+        best = min(best, time.perf_counter() - t)
+        del res
+    out["python_list_bytes"] = {"value": m / best, "wall_ms": best * 1e3, "records": m,
+                                "what": f"pyruhvro_amd.deserialize_array_threaded(list[bytes], schema, {num_chunks}) on a {m}-record sample"}
+    return out
 
 
 def run(args, make_step=None, backend="nccl"):
@@ -246,6 +296,8 @@ def main(argv=None):
     }
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n), num_chunks)
+    if not args.no_end_to_end and world == 1:
+        out["end_to_end"] = end_to_end(gen_cfg, SCHEMAS[gen_cfg], n, num_chunks)
     print(json.dumps(out))
 
 

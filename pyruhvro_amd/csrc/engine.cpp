@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <condition_variable>
 #include <mutex>
@@ -32,7 +33,8 @@ extern "C" {
 int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream);
 int rh_launch_scan(const rh::KParams* P, void* stream);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
-                   void* stream);
+                   const unsigned long long* ctrl, void* stream);
+int rh_launch_layout(const rh::LParams* L, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
@@ -217,6 +219,10 @@ struct rh_schema {
   std::map<int, DeviceProgram> dev;
   std::map<int, SpecKernel> spec;
   std::map<int, SpecKernel> espec;   // Arrow -> Avro kernels (rh_espec_size / rh_espec_emit)
+  // Arena bytes per (payload byte + 64 B per record) that the last decode of this schema needed: sizes the arena of
+  // the next call BEFORE its totals are known, so that the call is one stream submission (decode_device_impl1).
+  // 0 = no history yet (the first call of a schema lays its arena out on the host, after the scan).
+  std::atomic<double> arena_ratio{0.0};
 };
 
 namespace {
@@ -608,7 +614,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
 
   // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
-  const uint64_t o_null = 16;
+  const uint64_t o_null = 32;     // control words first (program.h): first_bad, layout flag, arena bytes used
   const uint64_t o_tot = align_up(o_null + 4ull * nnodes * k, 8);
   const uint64_t ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
   const uint64_t o_err = ctrl_bytes;
@@ -672,91 +678,134 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     throw DecodeError(format_error(ei));
   };
 
-  ev.rec(0, stream);
+  // ---- the launch sequence.  With a size history for this schema the whole call is ONE stream submission:
+  //   k_size -> k_scan -> k_layout (exact arena layout on the device, program.h LParams) -> k_init -> k_emit -> one D2H
+  // of the control words.  The arena is reserved up front from the history; when it turns out too small (the data
+  // changed character), the layout kernel says so, init/emit return at once, and the host re-runs the tail with an
+  // exactly sized arena -- which is also what the first call of a schema does.
   std::vector<uint64_t> totals((size_t)K * k, 0);
+  const uint64_t n_entries = (uint64_t)k * std::max(nbuf, 0);
+  const uint64_t tab_bytes = align_up((uint64_t)std::max(nbuf, 1) * k * 16, kAlign);
+  Lease dtab(dev_pool(), tab_bytes, device);
+  uint64_t* const d_sizes = (uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
+  P.bufptr = (void* const*)dtab.ptr();
+  uint64_t exact = 0;
+  uint32_t emit_lds = 0;
+
+  // host statement of the layout (same rule, same table order as rh_k_layout): fills the result's tables
+  auto layout_host = [&]() {
+    r.dom_rows.assign((size_t)cs.ndom * k, 0);
+    for (uint32_t c = 0; c < k; c++) {
+      r.dom_rows[c] = n == 0 ? 0 : (c == k - 1 ? r.rows_last : r.sz);
+      for (int d = 1; d < cs.ndom; d++) r.dom_rows[(size_t)d * k + c] = totals[(size_t)(d - 1) * k + c];
+    }
+    r.data_bytes = totals;
+    for (auto t : totals)
+      if (t > 0x7FFFFFFFull) throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
+    if (sk)
+      for (int d = 1; d < cs.ndom; d++)
+        for (uint32_t c = 0; c < k; c++)
+          if (totals[(size_t)(d - 1) * k + c] >= (1ull << 28)) throw NeedWideIndex();
+    r.buf_off.assign((size_t)nbuf * k, 0);
+    r.buf_size.assign((size_t)nbuf * k, 0);
+    uint64_t off = 0;
+    exact = 0;
+    for (uint32_t c = 0; c < k; c++) {
+      for (int b = 0; b < nbuf; b++) {
+        const rh::BufDesc& d = cs.bufs[b];
+        uint64_t ex = 0;
+        const uint64_t sz = rh::buf_bytes(d.kind, r.rows(d.dom, c), d.kind == rh::BK_DATA ? totals[(size_t)d.counter * k + c] : 0, &ex);
+        r.buf_off[(size_t)b * k + c] = off;
+        r.buf_size[(size_t)b * k + c] = sz;
+        off += rh::buf_slot_bytes(sz);
+        exact += ex;
+      }
+    }
+    r.arena_bytes = std::max<uint64_t>(off, kAlign);
+    r.output_bytes = exact;
+  };
+  auto launch_tail = [&]() {     // k_init + k_emit through the device tables at dtab
+    if (nbuf > 0 && rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
+    ev.rec(3, stream);
+    if (n > 0) {
+      emit_lds = lds_bytes;
+      if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
+        throw HipError("k_emit launch failed");
+    }
+    ev.rec(4, stream);
+  };
+  auto exact_tail = [&]() {      // totals are on the host: exactly sized arena, tables from the host
+    layout_host();
+    r.arena = Lease(dev_pool(), r.arena_bytes, device);
+    Lease htab(pin_pool(), tab_bytes, device);
+    void** hptr = (void**)htab.ptr();
+    uint64_t* hsz = (uint64_t*)(htab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
+    for (uint32_t c = 0; c < k; c++)
+      for (int b = 0; b < nbuf; b++) {   // device tables are [chunk][buf]
+        hptr[(size_t)c * nbuf + b] = r.arena.ptr() + r.buf_off[(size_t)b * k + c];
+        hsz[(size_t)c * nbuf + b] = r.buf_size[(size_t)b * k + c];
+      }
+    HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(ws.ptr() + 8, 0, 8, stream));      // clear the layout flag of a refused optimistic attempt
+    launch_tail();
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));      // also keeps htab alive until the table copy is done
+    check_bad(hctrl.ptr());
+  };
+
+  static const bool two_sync = [] { const char* e = std::getenv("RUHVRO_HIP_TWO_SYNC"); return e && *e && *e != '0'; }();
+  const double ratio = s->arena_ratio.load();
+  const bool fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
+  ev.rec(0, stream);
   if (n > 0 && K > 0) {
     if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream) : rh_launch_size(&P, lds_bytes, stream))
       throw HipError("k_size launch failed");
     ev.rec(1, stream);
     if (rh_launch_scan(&P, stream)) throw HipError("k_scan launch failed");
     ev.rec(2, stream);
-    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    check_bad(hctrl.ptr());
-    std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
   } else {
     // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
     if (sk && n > 0) HIPCHK(hipMemsetAsync(ws.ptr() + o_flag, 0x02, 4ull * nblocks, stream));
     ev.rec(1, stream);
     ev.rec(2, stream);
   }
-
-  // ---- output arena layout (sizes are exact Arrow sizes, each buffer 256-byte aligned)
-  r.dom_rows.assign((size_t)cs.ndom * k, 0);
-  for (uint32_t c = 0; c < k; c++) {
-    r.dom_rows[c] = n == 0 ? 0 : (c == k - 1 ? r.rows_last : r.sz);
-    for (int d = 1; d < cs.ndom; d++) r.dom_rows[(size_t)d * k + c] = totals[(size_t)(d - 1) * k + c];
-  }
-  r.data_bytes = totals;
-  for (auto t : totals)
-    if (t > 0x7FFFFFFFull) throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
-  if (sk)
-    for (int d = 1; d < cs.ndom; d++)
-      for (uint32_t c = 0; c < k; c++)
-        if (totals[(size_t)(d - 1) * k + c] >= (1ull << 28)) throw NeedWideIndex();
-  r.buf_off.assign((size_t)nbuf * k, 0);
-  r.buf_size.assign((size_t)nbuf * k, 0);
-  uint64_t off = 0, exact = 0;
-  for (uint32_t c = 0; c < k; c++) {
-    for (int b = 0; b < nbuf; b++) {
-      const rh::BufDesc& d = cs.bufs[b];
-      const uint64_t rows = r.rows(d.dom, c);
-      uint64_t sz = 0, ex = 0;
-      switch (d.kind) {
-        case rh::BK_BITMAP: sz = (rows + 63) / 64 * 8; ex = (rows + 7) / 8; break;
-        case rh::BK_VAL4: sz = ex = rows * 4; break;
-        case rh::BK_VAL8: sz = ex = rows * 8; break;
-        case rh::BK_I8: sz = ex = rows; break;
-        case rh::BK_OFFSETS: sz = ex = (rows + 1) * 4; break;
-        case rh::BK_DATA: sz = ex = totals[(size_t)d.counter * k + c]; break;
-      }
-      r.buf_off[(size_t)b * k + c] = off;
-      r.buf_size[(size_t)b * k + c] = sz;
-      off += align_up(std::max<uint64_t>(sz, 8), kAlign);
-      exact += ex;
+  const double basis = (double)payload + 64.0 * (double)n;
+  if (fused) {
+    const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
+    r.arena = Lease(dev_pool(), capacity, device);
+    rh::LParams LP;
+    std::memset(&LP, 0, sizeof LP);
+    LP.totals = P.totals; LP.desc = dp.desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
+    LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
+    LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
+    if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
+    launch_tail();
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    check_bad(hctrl.ptr());
+    if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
+    const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
+    if (lflag & rh::LF_CAPACITY) {
+      r.arena.release();
+      exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
+    } else {
+      layout_host();                             // throws for LF_OFFSET32 / LF_NEED_WIDE: same tests on the same totals
+      if (lflag) throw HipError("internal error: layout kernel and host disagree");
+      if (r.arena_bytes != std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign)) throw HipError("internal error: device and host arena layouts differ");
     }
-  }
-  r.arena_bytes = std::max<uint64_t>(off, kAlign);
-  r.output_bytes = exact;
-  r.arena = Lease(dev_pool(), r.arena_bytes, device);
-
-  // pointer + size tables -> device
-  const uint64_t tab_bytes = align_up((uint64_t)std::max(nbuf, 1) * k * 16, kAlign);
-  Lease htab(pin_pool(), tab_bytes, device);
-  Lease dtab(dev_pool(), tab_bytes, device);
-  void** hptr = (void**)htab.ptr();
-  uint64_t* hsz = (uint64_t*)(htab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
-  for (uint32_t c = 0; c < k; c++)
-    for (int b = 0; b < nbuf; b++) {   // device tables are [chunk][buf]
-      hptr[(size_t)c * nbuf + b] = r.arena.ptr() + r.buf_off[(size_t)b * k + c];
-      hsz[(size_t)c * nbuf + b] = r.buf_size[(size_t)b * k + c];
+  } else {
+    if (n > 0 && K > 0) {
+      HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      check_bad(hctrl.ptr());
+      std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
     }
-  HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
-  P.bufptr = (void* const*)dtab.ptr();
-  const uint64_t* d_sizes = (const uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
-
-  if (nbuf > 0 && rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, stream)) throw HipError("k_init launch failed");
-  ev.rec(3, stream);
-  uint32_t emit_lds = 0;
-  if (n > 0) {
-    emit_lds = lds_bytes;
-    if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
-      throw HipError("k_emit launch failed");
+    exact_tail();
   }
-  ev.rec(4, stream);
-  HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
-  check_bad(hctrl.ptr());
+  if (n > 0 && basis > 0) {
+    const double slots = (double)n_entries * (double)kAlign;
+    s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
+  }
   r.nullcount.assign((size_t)nnodes * k, 0);
   std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
 
@@ -896,32 +945,109 @@ struct TurnstilePass {      // RAII: a group that fails still lets the next one 
   ~TurnstilePass() { done(); }
 };
 
-// rows [0, n) of `offsets` (absolute byte offsets into `data`): H2D, the kernels, D2H -- all on `stream`.
-void decode_packed_range(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
-                         const ChunkGeo* geo, const rh_opts* opts, int device, hipStream_t stream, ArrowArray* out_chunks,
-                         uint32_t* out_k, rh_stats* stats, Turnstile* h2d_gate, Turnstile* d2h_gate, uint32_t ticket) {
-  const uint64_t lo = offsets[0], hi = offsets[n];
-  // the kernels index the payload with the absolute offsets: hand them a (virtual) base such that base + lo is where
-  // the range's first byte lands, congruent to lo modulo 16 so that the 16-byte window rows stay aligned
-  const uint64_t lead = 16 + (lo & 15);
-  const uint64_t o_off = align_up(lead + (hi - lo) + 32, kAlign);
-  Lease din(dev_pool(), o_off + 8 * (n + 1), device);
+// Where a call's records are: packed (one payload + n+1 absolute offsets: rh_decode_packed, what the reference builds
+// at deserialize.rs:90) or one (pointer, length) slice per record (rh_decode: what src/lib.rs:29-33 extracts).
+struct Source {
+  const uint8_t* data = nullptr;
+  const uint64_t* offsets = nullptr;
+  const uint8_t* const* ptrs = nullptr;
+  const uint64_t* lens = nullptr;
+  bool slices() const { return ptrs != nullptr || (data == nullptr && offsets == nullptr); }
+};
+
+void run_threads(unsigned nt, const std::function<void(unsigned)>& f) {
+  if (nt <= 1) { f(0); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back(f, t);
+  for (auto& x : th) x.join();
+}
+
+// Rows [r0, r1) of the source: (gather +) H2D, the kernels, D2H -- all on `stream`.
+// Slices are gathered into pooled PINNED memory together with their offsets, laid out exactly like the device
+// staging buffer, so the range goes up in ONE copy (the reference's BinaryArray::from_vec, deserialize.rs:90, but
+// per shard -- a later shard gathers while an earlier one is on the wire -- and straight into DMA-able memory).
+void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uint64_t num_chunks, const ChunkGeo* geo_in,
+                  const rh_opts* opts, int device, hipStream_t stream, ArrowArray* out_chunks, uint32_t* out_k,
+                  rh_stats* stats, Turnstile* h2d_gate, Turnstile* d2h_gate, uint32_t ticket, unsigned pack_threads) {
+  const uint64_t n = r1 - r0;
   rh_opts o = default_opts();
   o.device = device;
   o.flags = opts ? opts->flags : 0;
   o.stream = (void*)stream;
-  float h2d = 0.f;
-  {
-    TurnstilePass pass(h2d_gate, ticket);
-    Timer th;
-    if (hi > lo) HIPCHK(hipMemcpyAsync(din.ptr() + lead, data + lo, hi - lo, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    h2d = th.ms();
+  float h2d = 0.f, pack_ms = 0.f;
+  Lease din, pin;
+  const uint8_t* base = nullptr;
+  const uint64_t* d_offsets = nullptr;
+  uint64_t data_end = 0;
+  ChunkGeo geo;
+  if (geo_in) geo = *geo_in;
+  if (src.slices()) {
+    Timer tp;
+    const uint8_t* const* ptrs = src.ptrs + r0;
+    const uint64_t* lens = src.lens + r0;
+    // pass 1: byte totals per thread range; pass 2: offsets + bytes
+    const unsigned nt = n >= 4096 ? std::max(1u, pack_threads) : 1u;
+    auto lo_of = [&](unsigned t) { return n * t / nt; };
+    std::vector<uint64_t> part(nt + 1, 0);
+    run_threads(nt, [&](unsigned t) {
+      uint64_t sum = 0;
+      for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) sum += lens[i];
+      part[t + 1] = sum;
+    });
+    for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
+    const uint64_t tot = part[nt];
+    const uint64_t lead = 16;
+    const uint64_t o_off = align_up(lead + tot + 32, kAlign);
+    const uint64_t total_bytes = o_off + 8 * (n + 1);
+    pin = Lease(pin_pool(), total_bytes, device);
+    uint8_t* hdst = pin.ptr() + lead;
+    uint64_t* hoff = (uint64_t*)(pin.ptr() + o_off);
+    run_threads(nt, [&](unsigned t) {
+      uint64_t pos = part[t];
+      for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) {
+        hoff[i] = pos;
+        std::memcpy(hdst + pos, ptrs[i], lens[i]);
+        pos += lens[i];
+      }
+    });
+    hoff[n] = tot;
+    pack_ms = tp.ms();
+    din = Lease(dev_pool(), total_bytes, device);
+    {
+      TurnstilePass pass(h2d_gate, ticket);
+      Timer th;
+      HIPCHK(hipMemcpyAsync(din.ptr(), pin.ptr(), total_bytes, hipMemcpyHostToDevice, stream));
+      if (h2d_gate || stats) HIPCHK(hipStreamSynchronize(stream));   // a gate orders the shards of one link; else the stream does
+      h2d = th.ms();
+    }
+    base = din.ptr() + lead;
+    d_offsets = (const uint64_t*)(din.ptr() + o_off);
+    data_end = tot;
+    geo.payload_bytes = tot;
+  } else {
+    const uint64_t* offsets = src.offsets + r0;
+    const uint64_t lo = offsets[0], hi = offsets[n];
+    // the kernels index the payload with the absolute offsets: hand them a (virtual) base such that base + lo is where
+    // the range's first byte lands, congruent to lo modulo 16 so that the 16-byte window rows stay aligned
+    const uint64_t lead = 16 + (lo & 15);
+    const uint64_t o_off = align_up(lead + (hi - lo) + 32, kAlign);
+    din = Lease(dev_pool(), o_off + 8 * (n + 1), device);
+    {
+      TurnstilePass pass(h2d_gate, ticket);
+      Timer th;
+      if (hi > lo) HIPCHK(hipMemcpyAsync(din.ptr() + lead, src.data + lo, hi - lo, hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
+      if (h2d_gate || stats) HIPCHK(hipStreamSynchronize(stream));
+      h2d = th.ms();
+    }
+    base = din.ptr() + lead - lo;
+    d_offsets = (const uint64_t*)(din.ptr() + o_off);
+    data_end = hi;
+    geo.payload_bytes = hi - lo;
   }
-  const uint8_t* base = din.ptr() + lead - lo;
-  std::unique_ptr<rh_device_result> r(decode_device_impl(s, base, (const uint64_t*)(din.ptr() + o_off), hi, n, num_chunks,
-                                                         &o, stats, geo));
+  std::unique_ptr<rh_device_result> r(decode_device_impl(s, base, d_offsets, data_end, n, num_chunks, &o, stats,
+                                                         geo_in ? &geo : nullptr));
+  pin.release();            // the staging copy is done (decode_device_impl synchronised the stream)
   float d2h = 0.f;
   {
     TurnstilePass pass(d2h_gate, ticket);
@@ -933,6 +1059,7 @@ void decode_packed_range(rh_schema* s, const uint8_t* data, const uint64_t* offs
   if (stats) {
     stats->h2d_ms = h2d;
     stats->d2h_ms = d2h;
+    stats->pack_ms = pack_ms;
   }
 }
 
@@ -955,11 +1082,11 @@ struct Shard {
   uint32_t ticket = 0;          // order among the shards of that device
 };
 
-int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
-                       const rh_opts* opts, ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, float pack_ms,
-                       bool source_pinned) {
+int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_chunks, const rh_opts* opts,
+                     ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats) {
   require_device();
   Timer total;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const uint32_t k = rh_clamp_chunks(n, num_chunks);
   std::memset(out_chunks, 0, sizeof(ArrowArray) * k);      // the failure paths release whatever was produced
   if (opts && opts->chunk_rows) throw std::invalid_argument("chunk_rows applies to rh_decode_device only");
@@ -972,7 +1099,20 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
   }
   hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
   if (multi && user_stream) throw std::invalid_argument("a multi-device call runs on the engine's own streams (stream must be NULL)");
-  const uint64_t bytes = n ? offsets[n] - offsets[0] : 0;
+  uint64_t bytes = 0;
+  if (src.slices()) {          // payload size decides whether the call is pipelined: a parallel sum of the lengths
+    const unsigned nt = n >= (1u << 16) ? std::min(hw, 16u) : 1u;
+    std::vector<uint64_t> part(nt, 0);
+    run_threads(nt, [&](unsigned t) {
+      uint64_t sum = 0;
+      for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; i++) sum += src.lens[i];
+      part[t] = sum;
+    });
+    for (uint64_t v : part) bytes += v;
+  } else {
+    bytes = n ? src.offsets[n] - src.offsets[0] : 0;
+  }
+  const bool source_pinned = src.slices();     // slices are gathered into pinned memory shard by shard
 
   // ---- the deal: which chunks go where
   std::vector<Shard> shards;
@@ -1002,12 +1142,9 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
     // group's results out while the next group's records come in.
     const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned)) ? std::min<uint32_t>(k, 8) : 1;
     if (groups <= 1) {
-      decode_packed_range(s, data, offsets, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats,
-                          nullptr, nullptr, 0);
-      if (stats) {
-        stats->pack_ms = pack_ms;
-        stats->total_ms = total.ms() + pack_ms;
-      }
+      decode_range(s, src, 0, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats, nullptr, nullptr, 0,
+                   bytes >= (4u << 20) ? std::min(hw, 16u) : 1u);
+      if (stats) stats->total_ms = total.ms();
       return RH_OK;
     }
     gate_device.push_back(device);
@@ -1023,6 +1160,8 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
 
   const uint64_t sz = n / k, rows_last = n - (uint64_t)(k - 1) * sz;
   const size_t ns = shards.size();
+  // every shard gathers its own slices (in parallel with the others): share the host cores between them
+  const unsigned pack_threads = std::max(1u, std::min(hw, 32u) / (unsigned)std::max<size_t>(ns, 1));
   std::vector<rh_stats> gstats(ns);
   for (auto& gs : gstats) std::memset(&gs, 0, sizeof gs);
   std::vector<std::exception_ptr> failed(ns);
@@ -1044,10 +1183,10 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
           geo.k = sh.c1 - sh.c0;
           geo.sz = sz;
           geo.rows_last = sh.c1 == k ? rows_last : sz;
-          geo.payload_bytes = offsets[r1] - offsets[r0];
+          geo.payload_bytes = 0;           // decode_range fills it in
           Timer tsh;
-          decode_packed_range(s, data, offsets + r0, r1 - r0, 0, &geo, &sopts, sh.device, st, out_chunks + sh.c0, nullptr,
-                              want ? &gstats[g] : nullptr, &h2d_gates[sh.gate], &d2h_gates[sh.gate], sh.ticket);
+          decode_range(s, src, r0, r1, 0, &geo, &sopts, sh.device, st, out_chunks + sh.c0, nullptr,
+                       want ? &gstats[g] : nullptr, &h2d_gates[sh.gate], &d2h_gates[sh.gate], sh.ticket, pack_threads);
           gstats[g].total_ms = tsh.ms();
         }
       } catch (...) {
@@ -1079,6 +1218,7 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
       stats->blocks += gs.blocks;
       rh_stats& d = per_dev[shards[g].gate];
       d.h2d_ms += gs.h2d_ms; d.size_kernel_ms += gs.size_kernel_ms; d.scan_kernel_ms += gs.scan_kernel_ms;
+      stats->pack_ms = std::max(stats->pack_ms, gs.pack_ms);      // the shards gather side by side
       d.emit_kernel_ms += gs.emit_kernel_ms; d.d2h_ms += gs.d2h_ms;
       if (gs.records) { stats->specialized = gs.specialized; stats->lds_bytes = gs.lds_bytes; }
     }
@@ -1088,8 +1228,7 @@ int decode_packed_impl(rh_schema* s, const uint8_t* data, const uint64_t* offset
       stats->emit_kernel_ms = std::max(stats->emit_kernel_ms, d.emit_kernel_ms); stats->d2h_ms = std::max(stats->d2h_ms, d.d2h_ms);
     }
     stats->chunks = k;
-    stats->pack_ms = pack_ms;
-    stats->total_ms = total.ms() + pack_ms;
+    stats->total_ms = total.ms();
   }
   return RH_OK;
 }
@@ -1231,7 +1370,10 @@ int rh_decode_packed(const rh_schema* s, const uint8_t* data, const uint64_t* of
                      const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !offsets || !out_chunks) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
-    return decode_packed_impl(const_cast<rh_schema*>(s), data, offsets, n, num_chunks, opts, out_chunks, out_k, stats, 0.f, false);
+    Source src;
+    src.data = data;
+    src.offsets = offsets;
+    return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, opts, out_chunks, out_k, stats);
   });
 }
 
@@ -1239,30 +1381,10 @@ int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* le
               const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !out_chunks || (n && (!ptrs || !lens))) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
-    require_device();
-    // gather the record slices into one pinned buffer (the reference's BinaryArray::from_vec,
-    // deserialize.rs:90, but parallel and straight into DMA-able memory)
-    Timer tp;
-    std::vector<uint64_t> offsets(n + 1);
-    uint64_t tot = 0;
-    for (uint64_t i = 0; i < n; i++) { offsets[i] = tot; tot += lens[i]; }
-    offsets[n] = tot;
-    Lease pin(pin_pool(), tot + 16, 0);
-    uint8_t* dst = pin.ptr();
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
-    if (tot < (4u << 20)) nt = 1;
-    auto work = [&](uint64_t lo, uint64_t hi) {
-      for (uint64_t i = lo; i < hi; i++) std::memcpy(dst + offsets[i], ptrs[i], lens[i]);
-    };
-    if (nt == 1) work(0, n);
-    else {
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
-      for (auto& x : th) x.join();
-    }
-    const float pack_ms = tp.ms();
-    return decode_packed_impl(const_cast<rh_schema*>(s), dst, offsets.data(), n, num_chunks, opts, out_chunks, out_k,
-                              stats, pack_ms, true);
+    Source src;          // the record slices are gathered per shard, inside decode_range
+    src.ptrs = ptrs;
+    src.lens = lens;
+    return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, opts, out_chunks, out_k, stats);
   });
 }
 

@@ -211,11 +211,71 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {
 }
 
 // --------------------------------------------------------------------------
+// k_layout: one workgroup.  Entry e = chunk * nbuf + buf of the [chunk][buf] tables gets its arena slot: an exclusive
+// scan of the slot sizes in table order (each thread owns a contiguous run of entries, the 256 run sums are scanned
+// in LDS).  Replaces the host round trip (totals to the host, layout there, tables back) of round 1.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t layout_entry(const LParams& L, uint32_t e, uint32_t& flag) {
+  const uint32_t c = e / (uint32_t)L.nbuf, b = e - c * (uint32_t)L.nbuf;
+  const BufDesc d = L.desc[b];
+  const uint64_t rows0 = c == L.k - 1 ? L.rows_last : L.sz;
+  const uint64_t rows = d.dom == 0 ? rows0 : L.totals[(size_t)(d.dom - 1) * L.k + c];
+  const uint64_t tot = d.kind == BK_DATA ? L.totals[(size_t)d.counter * L.k + c] : 0;
+  if (tot > 0x7FFFFFFFull || (d.dom != 0 && rows > 0x7FFFFFFFull)) flag |= LF_OFFSET32;
+  if (L.narrow && d.dom != 0 && rows >= (1ull << 28)) flag |= LF_NEED_WIDE;
+  return buf_bytes(d.kind, rows, tot, nullptr);
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {
+  __shared__ uint64_t run_sum[kBlock];
+  __shared__ uint32_t flags;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t E = L.k * (uint32_t)L.nbuf;
+  const uint32_t per = (E + kBlock - 1) / kBlock;
+  const uint32_t e0 = tid * per < E ? tid * per : E, e1 = e0 + per < E ? e0 + per : E;
+  if (tid == 0) flags = 0;
+  __syncthreads();
+  uint32_t flag = 0;
+  uint64_t mine = 0;
+  for (uint32_t e = e0; e < e1; e++) mine += buf_slot_bytes(layout_entry(L, e, flag));
+  run_sum[tid] = mine;
+  if (flag) atomicOr(&flags, flag);
+  __syncthreads();
+  if (tid == 0) {          // 256 run sums: a serial exclusive scan is a few hundred cycles
+    uint64_t acc = 0;
+    for (int i = 0; i < kBlock; i++) { const uint64_t v = run_sum[i]; run_sum[i] = acc; acc += v; }
+    const uint64_t used = acc < kBufAlign ? kBufAlign : acc;
+    uint32_t f = flags;
+    if (used > L.capacity) f |= LF_CAPACITY;
+    L.ctrl[2] = used;
+    reinterpret_cast<uint32_t*>(L.ctrl)[2] = f;
+    flags = f;
+  }
+  __syncthreads();
+  if (flags) return;       // nothing may be written through these tables: leave them alone
+  uint64_t off = run_sum[tid];
+  uint32_t dummy = 0;
+  for (uint32_t e = e0; e < e1; e++) {
+    const uint64_t sz = layout_entry(L, e, dummy);
+    L.bufptr[e] = L.arena + off;
+    L.bufsize[e] = sz;
+    off += buf_slot_bytes(sz);
+  }
+}
+
+// true when the call must not emit: a malformed record was found by the size pass, or the layout kernel said no
+__device__ __forceinline__ bool call_aborted(const unsigned long long* ctrl) {
+  return ctrl[0] != 0 || reinterpret_cast<const uint32_t*>(ctrl)[2] != 0;
+}
+
+// --------------------------------------------------------------------------
 // k_init: offsets[0] = 0 for every offsets buffer, zero the atomically-built bitmaps.
 // grid = k * nbuf workgroups ([chunk][buf] tables)
 // --------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_init(void* const* bufptr, const uint64_t* bufsize,
-                                                              const BufDesc* desc, uint32_t nbuf, uint32_t k) {
+                                                              const BufDesc* desc, uint32_t nbuf, uint32_t k,
+                                                              const unsigned long long* ctrl) {
+  if (call_aborted(ctrl)) return;
   const uint32_t id = blockIdx.x % nbuf;
   const BufDesc d = desc[id];
   uint8_t* p = reinterpret_cast<uint8_t*>(bufptr[blockIdx.x]);
@@ -232,6 +292,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_init(void* const* bufp
 // --------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (call_aborted(P.first_bad)) return;
   const Smem s = carve(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Geo g = geometry(P, blockIdx.x);
@@ -294,9 +355,13 @@ extern "C" int rh_launch_scan(const rh::KParams* P, void* stream) {
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf,
-                              uint32_t k, void* stream) {
+                              uint32_t k, const unsigned long long* ctrl, void* stream) {
   hipLaunchKernelGGL(rh::rh_k_init, dim3(nbuf * k), dim3(rh::kBlock), 0, (hipStream_t)stream, bufptr, bufsize, desc,
-                     nbuf, k);
+                     nbuf, k, ctrl);
+  return (int)hipGetLastError();
+}
+extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
+  hipLaunchKernelGGL(rh::rh_k_layout, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, *L);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream) {

@@ -86,6 +86,57 @@ struct BufDesc {
   int32_t node;
 };
 
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define RH_HD __host__ __device__
+#else
+#define RH_HD
+#endif
+
+// Arena slot of one Arrow buffer of one chunk: `alloc` bytes are reserved (exact Arrow size, bitmaps rounded up to
+// whole 64-bit words so a wavefront's ballot store never leaves the slot), `exact` is the Arrow size.  ONE statement of
+// the layout rule, used by the device-side layout kernel (rh_k_layout) and by the host when it exports the buffers.
+RH_HD inline uint64_t buf_bytes(int32_t kind, uint64_t rows, uint64_t data_total, uint64_t* exact) {
+  uint64_t sz = 0, ex = 0;
+  switch (kind) {
+    case BK_BITMAP: sz = (rows + 63) / 64 * 8; ex = (rows + 7) / 8; break;
+    case BK_VAL4: sz = ex = rows * 4; break;
+    case BK_VAL8: sz = ex = rows * 8; break;
+    case BK_I8: sz = ex = rows; break;
+    case BK_OFFSETS: sz = ex = (rows + 1) * 4; break;
+    case BK_DATA: sz = ex = data_total; break;
+  }
+  if (exact) *exact = ex;
+  return sz;
+}
+constexpr uint64_t kBufAlign = 256;          // every buffer of every chunk starts on a 256-byte boundary
+RH_HD inline uint64_t buf_slot_bytes(uint64_t sz) { return ((sz < 8 ? 8 : sz) + kBufAlign - 1) / kBufAlign * kBufAlign; }
+
+// Control words at the head of a call's workspace (device), copied to the host once at the end of the call.
+//   [0] u64 first_bad   ~index of the lowest malformed record, 0 if none (k_size / k_emit, atomicMax)
+//   [1] u32 layout_flag set by rh_k_layout: the emit pass must not run (k_init / k_emit return at once)
+enum LayoutFlag : uint32_t {
+  LF_CAPACITY = 1,     // the arena reserved from the schema's size history is too small: the host re-runs the tail exactly
+  LF_OFFSET32 = 2,     // a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets
+  LF_NEED_WIDE = 4,    // a child row domain reaches 2^28 rows: only the generic kernels index that far
+};
+
+// Parameters of rh_k_layout (one workgroup): exact arena layout on the device from the scanned totals, so that a
+// call is ONE stream submission (k_size -> k_scan -> k_layout -> k_init -> k_emit) with no host round trip in between.
+struct LParams {
+  const uint64_t* totals;    // [K][k] from k_scan
+  const BufDesc* desc;       // [nbuf]
+  uint64_t sz, rows_last;    // chunk geometry (rows)
+  uint64_t n;
+  uint32_t k;
+  int32_t nbuf, K, ndom;
+  uint8_t* arena;
+  uint64_t capacity;         // bytes reserved at `arena`
+  void** bufptr;             // out [k][nbuf]
+  uint64_t* bufsize;         // out [k][nbuf] (allocated bytes)
+  unsigned long long* ctrl;  // control words (see above); ctrl[2] receives the arena bytes used
+  uint32_t narrow;           // 1: the schema-specialised kernels will run (32-bit in-buffer byte offsets)
+};
+
 // Kernel parameters (one launch = all chunks of one call on one device).
 struct KParams {
   const uint8_t* data;       // packed Avro payload

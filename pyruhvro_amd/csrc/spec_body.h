@@ -202,6 +202,8 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
 template <class S>
 __device__ __forceinline__ void spec_emit(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // the size pass found a malformed record, or the layout kernel refused (program.h LayoutFlag): nothing to emit
+  if (P.first_bad[0] != 0 || reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;

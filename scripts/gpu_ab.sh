@@ -7,7 +7,7 @@ mkdir -p $OUT
 for v in "$@"; do
   name=${v:-default}; name=${name//,/+}
   export RUHVRO_HIP_VARIANT=$v
-  timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end > $OUT/bench_$name.json 2> $OUT/bench_$name.err
   timeout 200 python scripts/parity_quick.py > $OUT/parity_$name.log 2>&1; rc=$?
   python - <<PY
 import json

@@ -4,7 +4,7 @@ TAG=${1:-iter}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
+timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end > $OUT/bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
 python - <<PY
 import json
 d=json.load(open("$OUT/bench.json"))

@@ -6,7 +6,7 @@ mkdir -p $OUT
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_gpu.log
 for w in full10m cfg3_1m flat4_1m; do
  for kf in ${KERNELS:-specialized generic}; do
-  timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --kernel $kf > $OUT/bench_$w.json 2> $OUT/bench_$w.err || tail -5 $OUT/bench_$w.err
+  timeout 300 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --kernel $kf > $OUT/bench_$w.json 2> $OUT/bench_$w.err || tail -5 $OUT/bench_$w.err
   python - <<PY
 import json
 try:

@@ -13,7 +13,7 @@ for v in "${VARS[@]}"; do
   name=${v:-default}; name=${name//,/+}
   export RUHVRO_HIP_VARIANT=$v
   timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $OUT/pytest_$name.log 2>&1; rc=$?
-  timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_$name.json 2> $OUT/bench_$name.err
+  timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end > $OUT/bench_$name.json 2> $OUT/bench_$name.err
   python - <<PY
 import json
 try:
