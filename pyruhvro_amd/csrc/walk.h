@@ -85,6 +85,11 @@ struct LdsSrc {
     r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
     return r;
   }
+  // 4 bytes at any byte position from ONE ds_read2_b32 and one v_alignbyte
+  __device__ __forceinline__ uint32_t ld4(uint32_t p) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    return __builtin_amdgcn_alignbyte(a[1], a[0], p & 3u);
+  }
   // >= 5 valid bytes (a 1-byte union branch + a varint of <= 4 bytes) from ONE ds_read2_b32
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
@@ -107,6 +112,7 @@ struct GlobalSrc {
     return x;
   }
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
+  __device__ __forceinline__ uint32_t ld4(uint32_t p) const { return (uint32_t)ld8(p); }
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
     const uint64_t lo = ld8(p), hi = ld8(p + 8);
     v4w r;
@@ -273,6 +279,19 @@ __device__ __forceinline__ bool varint32(uint32_t y, uint32_t avail, uint32_t& r
   return t != 0 && n <= avail;
 }
 
+// The varints that are small in practice -- string lengths, union / enum indices, block counts -- take a two-byte
+// form on the fast walk: raw value (14 bits) and byte length of a varint of <= 2 bytes at bit 0 of y.  Longer ones
+// (a string of 8 KiB and more, ...) are an anomaly there and go to the careful walk, like any other wire form
+// outside the single-read path.
+// (k_size 0.375 -> 0.358 ms on the full schema, profiles/r02d_variants_ab.txt; the size pass is VALU-issue bound.)
+constexpr bool kNarrow = true;
+__device__ __forceinline__ bool varint16(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
+  const uint32_t m = (uint32_t)((int32_t)(y << 24) >> 31);     // all ones when byte 0 carries a continuation flag
+  raw = ((((y >> 8) & 0x7Fu) & m) << 7) | (y & 0x7Fu);
+  n = 1u - m;                                                   // 1 or 2
+  return (y & 0x8080u) != 0x8080u && n <= avail;
+}
+
 // same for <= nx (<= 8) bytes at bit 0 of x, full 64-bit value
 __device__ __forceinline__ bool varint64(uint64_t x, uint32_t nx, uint32_t avail, int64_t& out, uint32_t& n) {
   const uint64_t t = ~x & 0x8080808080808080ull;
@@ -317,9 +336,10 @@ __device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nul
 // varint when isval && want_varint.  L.cur moves past what was read.
 template <bool CAREFUL, bool TRUST = false, class Src>
 __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
-                                         bool wide, int64_t& v) {
+                                         bool wide, int64_t& v, bool small = false) {
   if (!nullable && !want_varint) return dec;
-  const uint64_t x = (want_varint && wide) ? src.ld8(L.cur) : src.ld5(L.cur);
+  const bool narrow = kNarrow && small && !wide;      // `small`: a length / index / count (see varint16)
+  const uint64_t x = (want_varint && wide) ? src.ld8(L.cur) : (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
   const uint32_t avail = L.end - L.cur;
   uint32_t skip = 0;
   bool okb = true, isval = dec;
@@ -339,7 +359,7 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
       okv = varint64(y, nullable ? 7 : 8, av, v, n);
     } else {
       uint32_t raw;
-      okv = varint32((uint32_t)y, av, raw, n);
+      okv = narrow ? varint16((uint32_t)y, av, raw, n) : varint32((uint32_t)y, av, raw, n);
       v = (int64_t)(int32_t)((raw >> 1) ^ (0u - (raw & 1u)));
     }
   }
@@ -450,7 +470,7 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   const bool act = L.live;
   const bool dec = act && L.pres;
   int64_t v = 0;
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v);
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, true);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   if (op.code == OP_STRING) {
@@ -522,7 +542,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   L.sstk = (L.sstk << 8) | 0xFFull;
   const bool dec = act && L.pres;
   int64_t idx = 0;
-  const bool got = read_head<CAREFUL, RH_TRUST>(src, L, dec, false, false, true, false, idx) && L.live;
+  const bool got = read_head<CAREFUL, RH_TRUST>(src, L, dec, false, false, true, false, idx, true) && L.live;
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
@@ -591,7 +611,8 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
   if (TRUST) {               // every block header of this tile took the one-read form below in the size pass, unclamped
     uint32_t raw, n;
-    (void)varint32((uint32_t)src.ld5(L.cur), 4u, raw, n);
+    if (kNarrow) (void)varint16(src.ld4(L.cur), 4u, raw, n);
+    else (void)varint32((uint32_t)src.ld5(L.cur), 4u, raw, n);
     if (need) {
       L.cur += n;
       if ((raw >> 1) == 0) L.live = false;
@@ -602,9 +623,9 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
     return true;
   }
   // common wire form: a small positive count, or the 0 terminator, in one byte..four bytes
-  const uint64_t x = src.ld5(L.cur);
+  const uint32_t x = kNarrow ? src.ld4(L.cur) : (uint32_t)src.ld5(L.cur);
   uint32_t raw, n;
-  const bool okv = varint32((uint32_t)x, L.end - L.cur, raw, n);
+  const bool okv = kNarrow ? varint16(x, L.end - L.cur, raw, n) : varint32(x, L.end - L.cur, raw, n);
   const bool fast = need && okv && (raw & 1u) == 0 && (op.buf2 > 0 || raw == 0);   // non-negative; zero-width items take the exact path
   const bool slow = need && !fast;
   if (fast) {

@@ -67,10 +67,10 @@ def main():
             s = s.replace("if (rewalk) {", "if (false) {")
             s = s.replace("  if (__any(L.redo)) {   //", "  if (false) {   //")      # k_size: no careful re-walk of the wave
             s = s.replace("  if (careful) {\n    spec_run_walk<S, true, true>", "  if (false) {\n    spec_run_walk<S, true, true>")
-            s, n = re.subn(r"  if \(fits\) \{\n((?:[^\n]*\n)*?)  \} else \{\n"
-                           r"    GlobalSrc src\{[^\n]*\n    S::template walk<EMIT, true>\(c, src, L\);\n  \}",
-                           r"  {\n\1  }", s)
+            s, n = re.subn(r"  \} else \{\n    GlobalSrc src\{[^\n]*\n    S::template walk<EMIT, true>\(c, src, L\);\n  \}",
+                           "  }", s)
             assert n == 1, "spec_run_walk changed: update tools/isa_hist.py"
+            s = s.replace("  if (fits) {\n    LdsSrc src{win};", "  {\n    LdsSrc src{win};")
             open(p, "w").write(s)
         open(os.path.join(tmp, "k.hip"), "w").write("#include <hip/hip_runtime.h>\n" + src)
         asm = os.path.join(tmp, "k.s")

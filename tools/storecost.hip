@@ -35,6 +35,20 @@ __global__ void k_store(uint8_t* buf, uint32_t region, uint32_t pitch, uint32_t 
   }
 }
 
+// two stores per iteration: the second one `delta` bytes after the first (same cache lines when delta is small: the
+// head + overlapping-tail pair of a short string copy), or in the other half of the region (different lines)
+template <int W>
+__global__ void k_store_pair(uint8_t* buf, uint32_t region, uint32_t pitch, uint32_t delta, int iters) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const uintptr_t base = reinterpret_cast<uintptr_t>(buf) + (size_t)wave * (region + 4096);
+  uint32_t off = lane * pitch;
+  for (int i = 0; i < iters; i++) {
+    st<W>(base, off & (region - 1), (uint32_t)i);
+    st<W>(base, (off + delta) & (region - 1), (uint32_t)i + 7);
+    off += 64 * pitch;
+  }
+}
+
 __global__ void k_atomic(uint32_t* buf, uint32_t region_words, uint32_t stride, int iters) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   uint32_t* base = buf + (size_t)wave * (region_words + 1024);
@@ -118,6 +132,26 @@ int main() {
       const double lanes = 64.0 / c.mod;
       printf("store w=%2d pitch=%3u mis=%u lanes=%2.0f %-28s: %.3f ms  %6.1f cycles/instr/CU  %7.1f GB/s useful\n", c.w, c.pitch, c.mis, lanes,
              c.what, best, best * 1e-3 * ghz * 1e9 / instr_per_cu, (double)blocks * 4 * iters * lanes * c.w / best / 1e6);
+    }
+    for (uint32_t delta : {4u, 8u, 64u, 2048u}) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_store_pair<16>, dim3(blocks), dim3(256), 0, 0, d, region, 20u, delta, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+      }
+      printf("store PAIR w=16 pitch=20, second store +%4u bytes: %.3f ms  %6.1f cycles/instr/CU\n", delta, best, best * 1e-3 * ghz * 1e9 / ((double)wpc * iters * 2));
+      best = 1e9f;
+      for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k_store_pair<8>, dim3(blocks), dim3(256), 0, 0, d, region, 11u, delta, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+      }
+      printf("store PAIR w= 8 pitch=11, second store +%4u bytes: %.3f ms  %6.1f cycles/instr/CU\n", delta, best, best * 1e-3 * ghz * 1e9 / ((double)wpc * iters * 2));
     }
     for (uint32_t stride : {1u, 3u, 40u}) {
       (void)hipEventRecord(e0);
