@@ -14,7 +14,8 @@ import numpy as np
 import pyarrow as pa
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libruhvro_hip.so")
+# RUHVRO_HIP_LIB: another build of the same library (the sanitizer build of _build.build_sanitized); never a fallback
+LIB_PATH = os.environ.get("RUHVRO_HIP_LIB") or os.path.join(_HERE, "libruhvro_hip.so")
 
 RH_OK, RH_ERR_SCHEMA, RH_ERR_DECODE, RH_ERR_RUNTIME, RH_ERR_ARGUMENT = range(5)
 

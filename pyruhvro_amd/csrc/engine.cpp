@@ -8,6 +8,7 @@
 // There is NO CPU decode fallback in this library: without a HIP device every
 // decode entry point fails with RH_ERR_RUNTIME.
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -316,6 +317,35 @@ std::string format_error(const rh::ErrInfo& e) {
   }
 }
 
+// roctx ranges around the stages of a call (gather, H2D, kernels, D2H, export) so that a rocprofv3 --marker-trace
+// timeline shows them.  The marker library is bound at run time: the one the profiler already loaded (RTLD_NOLOAD),
+// or, with RUHVRO_HIP_ROCTX=1, loaded by name; without either the ranges cost one predictable branch.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = std::getenv("RUHVRO_HIP_ROCTX");
+    const bool want = e && *e && *e != '0';
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_LAZY | RTLD_NOLOAD);
+      if (!h && want) h = dlopen(name, RTLD_LAZY);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+  static const Roctx& get() { static const Roctx r; return r; }
+};
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(Roctx::get().push != nullptr) { if (on) Roctx::get().push(name); }
+  ~Range() { if (on) Roctx::get().pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
+
 rh_opts default_opts() {
   rh_opts o;
   std::memset(&o, 0, sizeof o);
@@ -556,6 +586,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
 rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
                                       uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo) {
   const CompiledSchema& cs = *s->cs;
+  Range rk("ruhvro_hip:decode_device (k_size, k_scan, k_layout, k_init, k_emit)");
   int device = 0;
   if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
   else HIPCHK(hipGetDevice(&device));
@@ -982,6 +1013,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   ChunkGeo geo;
   if (geo_in) geo = *geo_in;
   if (src.slices()) {
+    Range rg("ruhvro_hip:gather");
     Timer tp;
     const uint8_t* const* ptrs = src.ptrs + r0;
     const uint64_t* lens = src.lens + r0;
@@ -1015,6 +1047,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
     din = Lease(dev_pool(), total_bytes, device);
     {
       TurnstilePass pass(h2d_gate, ticket);
+      Range rh("ruhvro_hip:h2d");
       Timer th;
       HIPCHK(hipMemcpyAsync(din.ptr(), pin.ptr(), total_bytes, hipMemcpyHostToDevice, stream));
       if (h2d_gate || stats) HIPCHK(hipStreamSynchronize(stream));   // a gate orders the shards of one link; else the stream does
@@ -1034,6 +1067,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
     din = Lease(dev_pool(), o_off + 8 * (n + 1), device);
     {
       TurnstilePass pass(h2d_gate, ticket);
+      Range rh("ruhvro_hip:h2d");
       Timer th;
       if (hi > lo) HIPCHK(hipMemcpyAsync(din.ptr() + lead, src.data + lo, hi - lo, hipMemcpyHostToDevice, stream));
       HIPCHK(hipMemcpyAsync(din.ptr() + o_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, stream));
@@ -1051,6 +1085,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   float d2h = 0.f;
   {
     TurnstilePass pass(d2h_gate, ticket);
+    Range rd("ruhvro_hip:d2h+export");
     Timer td;
     to_host_impl(r.get(), out_chunks, stream);
     d2h = td.ms();

@@ -1,0 +1,49 @@
+"""Every schema whose specialised kernels should be in the kernel cache before a GPU run: the benchmark schemas plus
+every schema the parity tests decode.  Lives outside the product package because it imports the test suite's case
+tables (which use the oracle's schema model): build() and tests/conftest.py call it, pyruhvro_amd never does.
+
+    python scripts/known_schemas.py        # prebuild all of them (hiprtc, gfx950; needs no GPU)
+"""
+import os
+import sys
+from typing import List
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def known_schemas() -> List[str]:
+    """Benchmark schemas + every schema the parity tests decode."""
+    root = ROOT
+    from avrogen.schemas import SCHEMAS
+    out = list(SCHEMAS.values())
+    try:
+        import json
+        import cases
+        for c in cases.wire_cases() + cases.nesting_cases():
+            out.append(c[1])
+        for c in cases.error_cases():
+            out.append(c[1])
+        for c in cases.differential_cases():
+            out.append(c[1])
+        out.append(cases.logical_case()[0])
+        out += cases.encode_extra_schemas()
+        import random_cases
+        out += [random_cases.random_schema(seed) for seed in range(random_cases.PREBUILT_SEEDS)]
+        g = json.load(open(os.path.join(root, "tests", "golden", "reference_vectors.json")))
+        out += [json.dumps(s) for s in g["schemas"].values()]
+    except ImportError:
+        raise
+    return out
+
+
+
+
+if __name__ == "__main__":
+    from pyruhvro_amd.prebuild import prebuild_many
+    errs = prebuild_many(known_schemas(), verbose=True)
+    for e in errs:
+        print(e[:2000])
+    sys.exit(1 if errs else 0)

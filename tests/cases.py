@@ -257,7 +257,7 @@ def nesting_cases():
 
 
 # schemas that only the Arrow -> Avro GPU tests use (tests/test_gpu_encode.py); listed here so that
-# pyruhvro_amd.prebuild.known_schemas() compiles their specialised kernels ahead of the GPU run
+# scripts/known_schemas.py compiles their specialised kernels ahead of the GPU run
 ENC_WINDOW_SCHEMA = json.dumps({"type": "record", "name": "r", "fields": [
     {"name": "id", "type": "long"}, {"name": "t", "type": "string"}, {"name": "o", "type": ["null", "string"]},
     {"name": "xs", "type": {"type": "array", "items": "string"}}]})

@@ -30,14 +30,16 @@ def _build_native():
 def _warm_kernel_cache(request, _build_native):
     """GPU runs force the schema-specialised kernels for every test schema.  build() normally left their code
     objects in pyruhvro_amd/_kcache (they travel with the tree); if the cache is cold on this box, compile them in
-    parallel once (hiprtc, ~30 s, `python -m pyruhvro_amd.prebuild`) instead of one by one inside the tests.  A no-op when everything is cached."""
+    parallel once (hiprtc, ~30 s, `python scripts/known_schemas.py`) instead of one by one inside the tests.  A no-op when everything is cached."""
     selected_gpu = any(item.get_closest_marker("gpu") for item in request.session.items)
     if selected_gpu and has_gpu():
         import subprocess
-        from pyruhvro_amd.prebuild import cache_looks_warm, known_schemas
+        from pyruhvro_amd.prebuild import cache_looks_warm
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from known_schemas import known_schemas
         if not cache_looks_warm(known_schemas()):
             # a fresh interpreter: this process already talks to the GPU and must not be forked
-            subprocess.run([sys.executable, "-m", "pyruhvro_amd.prebuild"], cwd=ROOT, check=True, timeout=900)
+            subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "known_schemas.py")], cwd=ROOT, check=True, timeout=900)
     yield
 
 

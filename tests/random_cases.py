@@ -17,7 +17,7 @@ PRIMS = ["int", "long", "float", "double", "boolean", "string",
          {"type": "long", "logicalType": "timestamp-micros"}]
 
 
-PREBUILT_SEEDS = 40      # seeds whose specialised kernels build() compiles ahead of the GPU run (prebuild.known_schemas)
+PREBUILT_SEEDS = 40      # seeds whose specialised kernels build() compiles ahead of the GPU run (scripts/known_schemas.py)
 
 
 def _rand_type(r: random.Random, depth: int, counter: List[int]):

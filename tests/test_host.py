@@ -170,12 +170,55 @@ def test_no_device_fails_loudly_no_cpu_fallback():
 
 
 def test_product_does_not_reference_the_oracle():
-    pkg = os.path.join(ROOT, "pyruhvro_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
-                txt = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in txt and "from oracle" not in txt and "oracle_walk" not in txt, f
+    """Nothing under pyruhvro_amd/ (nor the drop-in alias pyruhvro/) may import, link or execute the oracle -- directly
+    or through a module that does: every import of every product module is followed, and the oracle, the test
+    suite and its case tables must not be reachable.  Native sources are searched for the oracle's symbols."""
+    import ast
+    banned = {"oracle", "tests", "cases", "random_cases", "conftest", "arrow_compare", "known_schemas", "hipmem"}
+    pkgs = [os.path.join(ROOT, "pyruhvro_amd"), os.path.join(ROOT, "pyruhvro")]
+    seen, todo = set(), []
+    for pkg in pkgs:
+        for dirpath, _, files in os.walk(pkg):
+            for f in files:
+                path = os.path.join(dirpath, f)
+                if f.endswith(".py"):
+                    todo.append(path)
+                elif f.endswith((".cpp", ".hip", ".h", ".hpp", ".inc")):
+                    txt = open(path).read()
+                    assert "oracle_walk" not in txt and "orc_decode" not in txt and "liboracle" not in txt, path
+
+    def resolve(mod):          # a module of THIS repository -> its file (third-party / stdlib modules are not followed)
+        rel = mod.replace(".", os.sep)
+        for cand in (os.path.join(ROOT, rel + ".py"), os.path.join(ROOT, rel, "__init__.py"),
+                     os.path.join(ROOT, "tests", rel + ".py"), os.path.join(ROOT, "scripts", rel + ".py")):
+            if os.path.exists(cand):
+                return cand
+        return None
+
+    while todo:
+        path = todo.pop()
+        if path in seen:
+            continue
+        seen.add(path)
+        tree = ast.parse(open(path).read(), path)
+        pkg_parts = os.path.relpath(os.path.dirname(path), ROOT).split(os.sep)
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                base = node.module or ""
+                if node.level:
+                    base = ".".join(pkg_parts[: len(pkg_parts) - node.level + 1] + ([node.module] if node.module else []))
+                mods = [base] + [base + "." + a.name for a in node.names]
+            for m in mods:
+                assert m.split(".")[0] not in banned, f"{os.path.relpath(path, ROOT)} imports {m}"
+                target = resolve(m)
+                if target:
+                    rel = os.path.relpath(target, ROOT).split(os.sep)[0]
+                    assert rel not in ("oracle", "tests", "scripts"), f"{os.path.relpath(path, ROOT)} reaches {os.path.relpath(target, ROOT)}"
+                    todo.append(target)
+    assert any(p.endswith(os.path.join("pyruhvro_amd", "prebuild.py")) for p in seen)
 
 
 def test_encode_binding_rejects_mismatched_batches_before_any_device_work():
