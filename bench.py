@@ -60,17 +60,24 @@ def parse_args(argv=None):
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--direction", default="decode", choices=["decode", "encode"],
+                    help="encode = the other direction (SURVEY 8f N1, rh_encode: Arrow -> Avro), a secondary line")
+    ap.add_argument("--rows", type=int, default=2_000_000, help="--direction encode: rows of the full schema")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = one list, whole chunks dealt to the ranks (BASELINE config 5); weak = the list per rank")
     return ap.parse_args(argv)
 
 
-def measured_traffic(kernel: str):
+def measured_traffic(kernel: str, schema_json: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/hbm_traffic.json, written by scripts/rocpd_summary.py --traffic-json from separate
-    FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied), or None."""
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied).  The file is stamped with the content
+    hash of the kernels it was measured on: a file from another kernel revision is REFUSED (None), never reported."""
     try:
+        from pyruhvro_amd import cabi
         d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        if d.get("_kernel_key") != cabi.kernel_key(schema_json):
+            return None
         return float(d[kernel]["hbm_bytes"])
     except Exception:
         return None
@@ -234,8 +241,55 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     return step, info
 
 
+def encode_main(args):
+    """Secondary line: Arrow -> Avro on the GPU (rh_encode; host RecordBatch in, host BinaryArrays out -- this
+    direction has no device-resident entry point, so `value` is PCIe-inclusive and says so; the kernels' own times and
+    the roofline of rh_espec_emit come from the engine's HIP events)."""
+    import numpy as np
+    import torch  # noqa: F401
+    import pyruhvro_amd as P
+    from avrogen import fastgen
+    from avrogen.schemas import SCHEMAS
+    from pyruhvro_amd import cabi
+    n, k = args.rows, 8
+    schema = SCHEMAS["full"]
+    data, offsets = fastgen.generate("full", n)
+    batch = cabi.decode_packed(data, offsets, schema, 1)[0]
+    P.set_kernel_mode({"auto": "auto", "generic": "generic", "specialized": "specialized"}[args.kernel])
+    for _ in range(args.warmup):
+        P.serialize_record_batch(batch, schema, k)
+    acc = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0, "h2d_ms": 0.0, "d2h_ms": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, st = P.serialize_record_batch_with_stats(batch, schema, k)
+        for key in acc:
+            acc[key] += st[key]
+    wall = time.perf_counter() - t0
+    total = sum(int(np.frombuffer(a.buffers()[1], dtype=np.int32, count=len(a) + 1)[-1]) for a in out)
+    assert total == int(offsets[-1]), "re-encoded bytes differ in size from the generator's datums"
+    for key in acc:
+        acc[key] /= args.steps
+    alg = st["input_bytes"] + total + 4 * (n + k)           # Arrow bytes in + Avro bytes out + i32 offsets out
+    emit_ms = acc["emit_kernel_ms"]
+    kern_ms = acc["size_kernel_ms"] + acc["scan_kernel_ms"] + emit_ms
+    print(json.dumps({
+        "metric": "Arrow rows/sec -> Avro (rh_encode, host batch in -> host BinaryArrays out, PCIe inclusive)",
+        "value": n * args.steps / wall, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic (the decode workload's records, decoded to Arrow on the GPU, then re-encoded)",
+        "config": {"workload": f"{n} rows of the generate_avro.py schema, num_chunks={k}, Arrow -> Avro (SURVEY 8f N1; not the headline metric)",
+                   "arrow_bytes_in": int(st["input_bytes"]), "avro_bytes_out": total, "kernel_ms": {"e_size": acc["size_kernel_ms"], "k_scan": acc["scan_kernel_ms"], "e_emit": emit_ms},
+                   "rows_per_s_kernels_only": n / (kern_ms * 1e-3) if kern_ms else 0.0, "h2d_ms": acc["h2d_ms"], "d2h_ms": acc["d2h_ms"],
+                   "kernel_form": "schema-specialised" if st.get("specialized") else "generic interpreter"},
+        "roofline": {"bound": "hbm", "kernel": "rh_espec_emit" if st.get("specialized") else "rh_e_emit", "achieved": alg / (emit_ms * 1e-3) / 1e9 if emit_ms else 0.0,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if emit_ms else 0.0,
+                     "traffic": None, "algorithmic_bytes_per_launch": int(alg), "bytes_per_record": alg / n, "avg_launch_ms": emit_ms}}))
+
+
 def main(argv=None):
     args = parse_args(argv)
+    if args.direction == "encode":
+        return encode_main(args)
     global KERNEL
     KERNEL = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
     import torch  # noqa: F401  (first: our library must share torch's HIP runtime)
@@ -290,7 +344,7 @@ def main(argv=None):
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": {"bound": "hbm", "kernel": emit_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic(emit_kernel) if args.workload == "full10m" else None,
+                     "traffic": measured_traffic(emit_kernel, SCHEMAS[gen_cfg]) if args.workload == "full10m" and args.scaling == "strong" or world == 1 and args.workload == "full10m" else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "bytes_per_record": alg_bytes / max(rs["records"], 1), "avg_launch_ms": emit_ms},
     }

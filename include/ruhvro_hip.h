@@ -149,6 +149,10 @@ void rh_device_result_free(rh_device_result* r);
  * needs no GPU) and stores the code objects (decode pair and encode pair) in the kernel cache so later
  * processes only load them; returns 0 and sets *cached = 1 when both were already there. */
 char* rh_schema_kernel_source(const rh_schema* s);
+/* Content hash (hex, malloc'd) of this schema's specialised decode (encode = 0) or encode (1) kernel pair: generated
+ * source + every device header it includes.  It is the kernel-cache key; measurement files (profiles/hbm_traffic.json)
+ * are stamped with it so that a number is only ever attributed to the kernel it was measured on. */
+char* rh_schema_kernel_key(const rh_schema* s, int encode);
 char* rh_schema_encode_kernel_source(const rh_schema* s);      /* the Arrow -> Avro pair (rh_encode) */
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err);
 

@@ -113,6 +113,8 @@ def lib():
         L.rh_schema_kernel_source.argtypes = [C.c_void_p]
         L.rh_schema_encode_kernel_source.restype = C.c_void_p
         L.rh_schema_encode_kernel_source.argtypes = [C.c_void_p]
+        L.rh_schema_kernel_key.restype = C.c_void_p
+        L.rh_schema_kernel_key.argtypes = [C.c_void_p, C.c_int]
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_device_count.restype = C.c_int
@@ -173,6 +175,18 @@ def kernel_source(schema_json: str) -> str:
     p = L.rh_schema_kernel_source(Schema.get(schema_json).handle)
     if not p:
         raise RuntimeError("rh_schema_kernel_source failed")
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.rh_free_string(p)
+
+
+def kernel_key(schema_json: str, encode: bool = False) -> str:
+    """Content hash of the schema's specialised kernel pair (rh_schema_kernel_key): the kernel-cache key."""
+    L = lib()
+    p = L.rh_schema_kernel_key(Schema.get(schema_json).handle, 1 if encode else 0)
+    if not p:
+        raise RuntimeError("rh_schema_kernel_key failed")
     try:
         return C.string_at(p).decode()
     finally:

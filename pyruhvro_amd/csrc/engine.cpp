@@ -755,8 +755,11 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     r.arena_bytes = std::max<uint64_t>(off, kAlign);
     r.output_bytes = exact;
   };
-  auto launch_tail = [&]() {     // k_init + k_emit through the device tables at dtab
-    if (nbuf > 0 && rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
+  bool child_bitmaps = false;     // bitmaps of child row domains are built with atomics on zeroed words
+  for (const rh::BufDesc& d : cs.bufs) child_bitmaps = child_bitmaps || (d.kind == rh::BK_BITMAP && d.dom != 0);
+  auto launch_tail = [&](bool offsets_done) {     // k_init + k_emit through the device tables at dtab
+    if (nbuf > 0 && (child_bitmaps || !offsets_done) &&
+        rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
     ev.rec(3, stream);
     if (n > 0) {
       emit_lds = lds_bytes;
@@ -778,7 +781,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       }
     HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(ws.ptr() + 8, 0, 8, stream));      // clear the layout flag of a refused optimistic attempt
-    launch_tail();
+    launch_tail(false);
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));      // also keeps htab alive until the table copy is done
     check_bad(hctrl.ptr());
@@ -810,7 +813,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
     LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
     if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
-    launch_tail();
+    launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     check_bad(hctrl.ptr());
@@ -1353,6 +1356,16 @@ char* rh_schema_kernel_source(const rh_schema* s) {
   if (!s) return nullptr;
   try {
     return dup_msg(rh::generate_kernel_source(*s->cs));
+  } catch (...) {
+    return nullptr;
+  }
+}
+
+char* rh_schema_kernel_key(const rh_schema* s, int encode) {
+  if (!s) return nullptr;
+  try {
+    const std::string src = encode ? rh::generate_encode_source(*s->cs) : rh::generate_kernel_source(*s->cs);
+    return dup_msg(rh::kernel_cache_key(src, encode != 0));
   } catch (...) {
     return nullptr;
   }

@@ -259,6 +259,9 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {
     const uint64_t sz = layout_entry(L, e, dummy);
     L.bufptr[e] = L.arena + off;
     L.bufsize[e] = sz;
+    // offsets[0] = 0 of every offsets buffer (what k_init does on the exact path; k_init then only has the
+    // atomically-built child-domain bitmaps left to zero, and is not launched at all for schemas without any)
+    if (L.desc[e % (uint32_t)L.nbuf].kind == BK_OFFSETS) *reinterpret_cast<uint32_t*>(L.arena + off) = 0;
     off += buf_slot_bytes(sz);
   }
 }

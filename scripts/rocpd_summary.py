@@ -52,9 +52,14 @@ def traffic(fetch_db: str, write_db: str) -> dict:
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 4 and sys.argv[1] == "--traffic-json":
+    if len(sys.argv) in (4, 5) and sys.argv[1] == "--traffic-json":
+        # --traffic-json <fetch.db> <write.db> [kernel_key]: the key (pyruhvro_amd.cabi.kernel_key of the schema the
+        # passes decoded) stamps the file; bench.py only reports the traffic when the kernels it runs carry that key
         import json
-        print(json.dumps(traffic(sys.argv[2], sys.argv[3]), indent=1))
+        d = traffic(sys.argv[2], sys.argv[3])
+        if len(sys.argv) == 5:
+            d["_kernel_key"] = sys.argv[4]
+        print(json.dumps(d, indent=1))
     else:
         for p in sys.argv[1:]:
             print(summarise(p))
