@@ -29,6 +29,20 @@ class Blocks:
     blocks: list
 
 
+@dataclass
+class Unscaled:
+    """A decimal's unscaled integer value (the wire carries its big-endian two's complement bytes).  `pad` extra sign
+    bytes make a non-minimal encoding (legal on a bytes base)."""
+    value: int
+    pad: int = 0
+
+
+@dataclass
+class UuidText:
+    """A uuid as the writer puts it on the wire: text for a string base, 16 raw bytes for a fixed(16) base."""
+    text: object
+
+
 def zigzag(n: int) -> bytes:
     u = ((n << 1) ^ (n >> 63)) & 0xFFFFFFFFFFFFFFFF
     out = bytearray()
@@ -48,8 +62,14 @@ def _fits(s: AvroSchema, v) -> bool:
         return v is None
     if k == "boolean":
         return isinstance(v, bool)
-    if k in ("int", "long", "date", "timestamp-millis", "timestamp-micros"):
+    if k in ("int", "long", "date", "timestamp-millis", "timestamp-micros", "time-millis", "time-micros"):
         return isinstance(v, int) and not isinstance(v, bool)
+    if k in ("bytes", "fixed"):
+        return isinstance(v, (bytes, bytearray))
+    if k == "decimal":
+        return isinstance(v, Unscaled)
+    if k == "uuid":
+        return isinstance(v, UuidText)
     if k in ("float", "double"):
         return isinstance(v, float)
     if k in ("string", "enum"):
@@ -69,8 +89,37 @@ def encode(s: AvroSchema, v, out: bytearray) -> None:
         return
     if k == "boolean":
         out.append(1 if v else 0)
-    elif k in ("int", "long", "date", "timestamp-millis", "timestamp-micros"):
+    elif k in ("int", "long", "date", "timestamp-millis", "timestamp-micros", "time-millis", "time-micros"):
         out += zigzag(int(v))
+    elif k == "bytes":
+        out += zigzag(len(v))
+        out += bytes(v)
+    elif k == "fixed":
+        assert len(v) == s.size, (len(v), s.size)
+        out += bytes(v)
+    elif k == "decimal":
+        u = v.value
+        if s.items.kind == "fixed":
+            out += u.to_bytes(s.items.size, "big", signed=True)
+        else:
+            n = 1
+            while True:
+                try:
+                    raw = u.to_bytes(n, "big", signed=True)
+                    break
+                except OverflowError:
+                    n += 1
+            raw = (b"\xff" if u < 0 else b"\x00") * v.pad + raw
+            out += zigzag(len(raw))
+            out += raw
+    elif k == "uuid":
+        if s.items.kind == "fixed":
+            assert isinstance(v.text, (bytes, bytearray)) and len(v.text) == 16
+            out += bytes(v.text)
+        else:
+            b = v.text if isinstance(v.text, bytes) else v.text.encode()
+            out += zigzag(len(b))
+            out += b
     elif k == "float":
         out += struct.pack("<f", v)
     elif k == "double":

@@ -300,6 +300,10 @@ def main(argv=None):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc) = run(args, gpu_step_factory, "nccl")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()          # clean teardown of the RCCL communicator on every rank
     if rank != 0:
         return
     # roofline of the dominant kernel, on the slowest rank's launch: SURVEY 8(d) B_in + 8 (u64 offset) + B_out per record

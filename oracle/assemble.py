@@ -60,6 +60,7 @@ def _validity(b: Buffers, always: bool):
 
 
 _NP = {
+    S.K_TIMEMILLI: np.int32, S.K_TIMEMICRO: np.int64,          # N4 (beyond the reference)
     S.K_INT: np.int32, S.K_DATE: np.int32,
     S.K_LONG: np.int64, S.K_TSMILLI: np.int64, S.K_TSMICRO: np.int64,
     S.K_FLOAT: np.uint32, S.K_DOUBLE: np.uint64,
@@ -89,8 +90,19 @@ def assemble(node: S.Node, b: Buffers) -> pa.Array:
     if k == S.K_BOOL:
         vb, nulls = _validity(b, always=False)
         return pa.Array.from_buffers(dt, n, [vb, _bitmap(np.asarray(b.values, dtype=bool))], null_count=nulls)
-    if k in (S.K_STRING, S.K_ENUM):
+    if k in (S.K_STRING, S.K_ENUM, S.K_BYTES):
         return _string_array(b, dt)
+    if k in (S.K_FIXED, S.K_UUID, S.K_DECIMAL):           # N4: fixed-width values, zero under nulls, lazy validity
+        vb, nulls = _validity(b, always=False)
+        w = 16 if k != S.K_FIXED else dt.byte_width
+        raw = bytearray()
+        for v in b.values:
+            if k == S.K_DECIMAL:
+                raw += int(v).to_bytes(16, "little", signed=True)
+            else:
+                raw += v if isinstance(v, (bytes, bytearray)) and len(v) == w else bytes(w)
+        assert len(raw) == w * n
+        return pa.Array.from_buffers(dt, n, [vb, pa.py_buffer(bytes(raw))], null_count=nulls)
     if k == S.K_RECORD:                                   # fast_decode.rs:618-639
         kids = [assemble(cn, cb) for cn, cb in zip(node.children, b.children)]
         vb, nulls = _validity(b, always=True) if node.nullable else (None, 0)

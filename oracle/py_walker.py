@@ -163,6 +163,8 @@ class _B:
             self._append_value(read_bool(c))
         elif k == S.K_STRING:
             self._append_str(read_string(c))
+        elif k in (S.K_BYTES, S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO):
+            self._decode_n4(c)
         elif k == S.K_ENUM:
             # append_enum, fast_decode.rs:570-578: `as usize` then symbols.get
             idx = read_zigzag_long(c) & 0xFFFFFFFFFFFFFFFF
@@ -171,6 +173,43 @@ class _B:
             self._append_str(self.node.symbols[idx].encode())
         else:
             raise AssertionError(k)
+
+    # ---- beyond the reference (Avro 1.11 specification wire forms) -------------------
+    def _decode_n4(self, c: _Cur):
+        n = self.node
+        k = n.kind
+        if k == S.K_TIMEMILLI:                   # int
+            self._append_value(_as_i32(read_zigzag_long(c)))
+        elif k == S.K_TIMEMICRO:                 # long
+            self._append_value(read_zigzag_long(c))
+        elif k == S.K_BYTES:                     # like string, no character set
+            self._append_str(read_string(c))
+        else:
+            if n.wire_size >= 0:                 # fixed: exactly `size` bytes, no prefix
+                if c.e - c.p < n.wire_size:
+                    raise DecodeError("unexpected end of buffer (fixed)")
+                raw = bytes(c.b[c.p:c.p + n.wire_size])
+                c.p += n.wire_size
+            else:
+                raw = read_string(c)
+            if k == S.K_FIXED:
+                self._append_value(raw)
+            elif k == S.K_DECIMAL:               # big-endian two's complement unscaled value -> i128
+                if len(raw) > 16:
+                    raise DecodeError(f"decimal value of {len(raw)} bytes does not fit Decimal128")
+                self._append_value(int.from_bytes(raw, "big", signed=True) if raw else 0)
+            else:                                # uuid: hex text (8-4-4-4-12 or 32 digits) or 16 raw bytes
+                if n.wire_size >= 0:
+                    self._append_value(raw)
+                else:
+                    txt = raw
+                    if len(txt) == 36:
+                        if any(txt[i] != 0x2D for i in (8, 13, 18, 23)):
+                            raise DecodeError("invalid uuid string")
+                        txt = txt[0:8] + txt[9:13] + txt[14:18] + txt[19:23] + txt[24:36]
+                    if len(txt) != 32 or any(ch not in b"0123456789abcdefABCDEF" for ch in txt):
+                        raise DecodeError("invalid uuid string")
+                    self._append_value(bytes.fromhex(txt.decode()))
 
     # ---- FieldDecoder::decode (fast_decode.rs:421-499) ------------------
     def decode(self, c: _Cur):
@@ -211,7 +250,7 @@ class _B:
         elif k in (S.K_LIST, S.K_MAP):           # 721-727, 764-770
             self.offsets.append(self.offsets[-1])
             self.valid.append(False)
-        elif k in (S.K_STRING, S.K_ENUM):
+        elif k in (S.K_STRING, S.K_ENUM, S.K_BYTES):
             self.valid.append(False)
             self.offsets.append(len(self.data))
         else:
@@ -272,9 +311,11 @@ class _B:
         if k in (S.K_INT, S.K_DATE, S.K_LONG, S.K_TSMILLI, S.K_TSMICRO, S.K_FLOAT, S.K_DOUBLE,
                  S.K_BOOL, S.K_UNION):
             b.values = list(self.values)
-        if k in (S.K_STRING, S.K_ENUM):
+        if k in (S.K_STRING, S.K_ENUM, S.K_BYTES):
             b.offsets = list(self.offsets)
             b.data = bytes(self.data)
+        if k in (S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO):
+            b.values = list(self.values)
         if k in (S.K_LIST, S.K_MAP):
             b.offsets = list(self.offsets)
         b.children = [ch.buffers() for ch in self.kids]
@@ -283,10 +324,11 @@ class _B:
         return b
 
 
-def decode(records: List[bytes], schema_json: str):
-    """fast_decode::decode (fast_decode.rs:806-835) -> pyarrow.RecordBatch."""
+def decode(records: List[bytes], schema_json: str, extended: bool = False):
+    """fast_decode::decode (fast_decode.rs:806-835) -> pyarrow.RecordBatch.  ``extended``: also the N4 leaf types the
+    reference's gate rejects (avro_schema.is_supported_extended)."""
     avro = S.parse_schema(schema_json)
-    arrow_schema, root = S.build_tree(avro)
+    arrow_schema, root = S.build_tree(avro, extended)
     top = _B(root)
     for rec in records:
         c = _Cur(bytes(rec))

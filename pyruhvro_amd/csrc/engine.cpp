@@ -313,6 +313,9 @@ std::string format_error(const rh::ErrInfo& e) {
       std::snprintf(buf, sizeof buf, "array/map block count %lld of zero-width items exceeds the supported range", (long long)e.detail);
       return buf;
     case rh::E_INTERNAL: return "internal error: the fast and the careful walk disagree on a record";
+    case rh::E_EOB_FIXED: return "unexpected end of buffer (fixed)";
+    case rh::E_DECIMAL: std::snprintf(buf, sizeof buf, "decimal value of %lld bytes does not fit Decimal128", (long long)e.detail); return buf;
+    case rh::E_UUID: return "invalid uuid string";
     default: return "decode error";
   }
 }
@@ -458,6 +461,9 @@ ArrowArray* export_node(const rh_device_result& r, int id, uint32_t c, const uin
       break;
     case rh::NK_STRING: case rh::NK_ENUM:
       init_array(a, len, nulls, {nulls > 0 ? bp(n.buf_validity) : nullptr, bp(n.buf_main), bp(n.buf_data)}, {});
+      break;
+    case rh::NK_BIN:        // FixedSizeBinary / Decimal128: lazy validity like every leaf builder, one values buffer
+      init_array(a, len, nulls, {nulls > 0 ? bp(n.buf_validity) : nullptr, bp(n.buf_main)}, {});
       break;
     case rh::NK_NULL:
       init_array(a, len, len, {}, {});
@@ -630,7 +636,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
   const SpecKernel* sk = nullptr;
   // the specialised kernels address every chunk buffer with 32-bit byte offsets
-  const bool narrow_ok = std::max(r.sz, r.rows_last) < (1ull << 28);
+  // (every chunk buffer below 4 GiB: at most max_row_bytes per row -- 16 unless the schema has a wider fixed)
+  const uint64_t narrow_rows = std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16));
+  const bool narrow_ok = std::max(r.sz, r.rows_last) < narrow_rows;
   if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
     const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
     const SpecKernel& k0 = spec_kernel(s, device, may_compile);
@@ -736,7 +744,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (sk)
       for (int d = 1; d < cs.ndom; d++)
         for (uint32_t c = 0; c < k; c++)
-          if (totals[(size_t)(d - 1) * k + c] >= (1ull << 28)) throw NeedWideIndex();
+          if (totals[(size_t)(d - 1) * k + c] >= narrow_rows) throw NeedWideIndex();
     r.buf_off.assign((size_t)nbuf * k, 0);
     r.buf_size.assign((size_t)nbuf * k, 0);
     uint64_t off = 0;
@@ -745,7 +753,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       for (int b = 0; b < nbuf; b++) {
         const rh::BufDesc& d = cs.bufs[b];
         uint64_t ex = 0;
-        const uint64_t sz = rh::buf_bytes(d.kind, r.rows(d.dom, c), d.kind == rh::BK_DATA ? totals[(size_t)d.counter * k + c] : 0, &ex);
+        const uint64_t sz = rh::buf_bytes(d.kind, r.rows(d.dom, c), d.kind == rh::BK_DATA ? totals[(size_t)d.counter * k + c] : 0, &ex,
+                                          (uint32_t)d.counter);
         r.buf_off[(size_t)b * k + c] = off;
         r.buf_size[(size_t)b * k + c] = sz;
         off += rh::buf_slot_bytes(sz);
@@ -812,6 +821,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     LP.totals = P.totals; LP.desc = dp.desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
     LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
     LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
+    LP.narrow_rows = narrow_rows;
     if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
     launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
@@ -1364,6 +1374,7 @@ char* rh_schema_kernel_source(const rh_schema* s) {
 char* rh_schema_kernel_key(const rh_schema* s, int encode) {
   if (!s) return nullptr;
   try {
+    if (encode && !s->cs->encode_unsupported.empty()) return nullptr;
     const std::string src = encode ? rh::generate_encode_source(*s->cs) : rh::generate_kernel_source(*s->cs);
     return dup_msg(rh::kernel_cache_key(src, encode != 0));
   } catch (...) {
@@ -1372,7 +1383,7 @@ char* rh_schema_kernel_key(const rh_schema* s, int encode) {
 }
 
 char* rh_schema_encode_kernel_source(const rh_schema* s) {
-  if (!s) return nullptr;
+  if (!s || !s->cs->encode_unsupported.empty()) return nullptr;
   try {
     return dup_msg(rh::generate_encode_source(*s->cs));
   } catch (...) {
@@ -1386,8 +1397,12 @@ int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
     bool hit = false, ehit = false;
     std::vector<char> image = rh::get_kernel_image(*s->cs, true, &hit);
     if (image.empty()) throw std::runtime_error("kernel image empty");
-    image = rh::get_kernel_image(*s->cs, true, &ehit, true);       // and the Arrow -> Avro pair
-    if (image.empty()) throw std::runtime_error("encode kernel image empty");
+    if (s->cs->encode_unsupported.empty()) {
+      image = rh::get_kernel_image(*s->cs, true, &ehit, true);       // and the Arrow -> Avro pair
+      if (image.empty()) throw std::runtime_error("encode kernel image empty");
+    } else {
+      ehit = true;                                                   // decode-only schema (N4 types)
+    }
     if (cached) *cached = (hit && ehit) ? 1 : 0;
     return RH_OK;
   });
@@ -1637,6 +1652,9 @@ std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, 
 int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschema, uint64_t num_chunks, const rh_opts* opts,
                 ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats) {
   const CompiledSchema& cs = *s->cs;
+  if (!cs.encode_unsupported.empty())
+    throw rh::SchemaError("schema is outside the GPU encode path (" + cs.encode_unsupported +
+                          ": decoded on the GPU, SURVEY 8f N4, but not encoded)");
   Timer total;
   // schema / batch mismatches are reported before any device work, like the encoder construction of
   // fast_encode.rs:33-37 that runs before the first row is written

@@ -21,6 +21,7 @@ struct Value {
   std::vector<std::pair<std::string, Value>> obj;
 
   bool is_string() const { return type == String; }
+  bool is_number() const { return type == Number; }
   bool is_object() const { return type == Object; }
   bool is_array() const { return type == Array; }
   const Value* get(const char* key) const {

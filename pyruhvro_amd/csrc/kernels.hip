@@ -83,6 +83,7 @@ __device__ __forceinline__ void walk(const KParams& P, const ICtx& c, const Src&
         pc = op.b;
         continue;
       case OP_LIST_END: h_list_end<EMIT>(c, L, op); break;
+      case OP_BIN: h_bin<EMIT, true>(c, src, L, op); break;
       default: return;
     }
     pc++;
@@ -222,8 +223,8 @@ __device__ __forceinline__ uint64_t layout_entry(const LParams& L, uint32_t e, u
   const uint64_t rows = d.dom == 0 ? rows0 : L.totals[(size_t)(d.dom - 1) * L.k + c];
   const uint64_t tot = d.kind == BK_DATA ? L.totals[(size_t)d.counter * L.k + c] : 0;
   if (tot > 0x7FFFFFFFull || (d.dom != 0 && rows > 0x7FFFFFFFull)) flag |= LF_OFFSET32;
-  if (L.narrow && d.dom != 0 && rows >= (1ull << 28)) flag |= LF_NEED_WIDE;
-  return buf_bytes(d.kind, rows, tot, nullptr);
+  if (L.narrow && d.dom != 0 && rows >= L.narrow_rows) flag |= LF_NEED_WIDE;
+  return buf_bytes(d.kind, rows, tot, nullptr, (uint32_t)d.counter);
 }
 
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {

@@ -27,6 +27,15 @@ constexpr int kMaxUnionDepth = 8;    // nested N-variant unions (8-bit selector 
 
 enum FixedKind : int32_t { FK_I32 = 0, FK_I64 = 1, FK_F32 = 2, FK_F64 = 3, FK_BOOL = 4 };
 
+// OP_BIN sub-kinds (types the reference's schema translation maps -- schema_translate.rs:58,133-137 --
+// but its direct-decode gate rejects, fast_decode.rs:59; decoded here from the Avro 1.11 wire rules)
+enum BinKind : int32_t {
+  BN_FIXED = 0,      // fixed(N): N raw bytes                      -> FixedSizeBinary(N)   (also uuid on fixed(16))
+  BN_DEC_BYTES = 1,  // decimal on bytes: length + big-endian two's complement -> Decimal128 (16 bytes, little-endian)
+  BN_DEC_FIXED = 2,  // decimal on fixed(N <= 16): N bytes big-endian two's complement -> Decimal128
+  BN_UUID_STR = 3,   // uuid on string: 36-char hyphenated (or 32-char simple) hex text -> FixedSizeBinary(16)
+};
+
 enum OpCode : int32_t {
   OP_END = 0,
   OP_FIXED,        // int/long/float/double/boolean/date/timestamp leaf       (fast_decode.rs:424-432,434-473)
@@ -41,6 +50,7 @@ enum OpCode : int32_t {
   OP_LIST_NEXT,    // block header / loop head                                (689-700)
   OP_LIST_TAIL,    // end of one item
   OP_LIST_END,     // push offset
+  OP_BIN,          // fixed / decimal / uuid leaf (BinKind in a, wire bytes in b, output bytes per row in c)
 };
 
 enum OpFlags : int32_t {
@@ -69,6 +79,9 @@ enum ErrCode : uint32_t {
   E_OK = 0, E_EOB, E_VARINT, E_EOB_F32, E_EOB_F64, E_BOOL, E_NEGLEN, E_EOB_STR, E_ENUM, E_BRANCH, E_UNION,
   E_LIST_RANGE,   // zero-width items with a block count beyond the i32 offset range (no reference message)
   E_INTERNAL,     // the fast emit walk met a wire form the size pass had not flagged (cannot happen; never silent)
+  E_EOB_FIXED,    // N4 types (no reference message: the reference never decodes them)
+  E_DECIMAL,      // a decimal of more than 16 bytes
+  E_UUID,         // uuid text that is not 32 / 36 hex characters
 };
 
 struct ErrInfo {
@@ -77,12 +90,12 @@ struct ErrInfo {
   int64_t detail;
 };
 
-enum BufKind : int32_t { BK_BITMAP = 0, BK_VAL4, BK_VAL8, BK_I8, BK_OFFSETS, BK_DATA };
+enum BufKind : int32_t { BK_BITMAP = 0, BK_VAL4, BK_VAL8, BK_I8, BK_OFFSETS, BK_DATA, BK_FIXW };
 
 struct BufDesc {
   int32_t kind;
   int32_t dom;      // row domain
-  int32_t counter;  // BK_DATA: counter id giving its byte length
+  int32_t counter;  // BK_DATA: counter id giving its byte length | BK_FIXW: bytes per row
   int32_t node;
 };
 
@@ -95,9 +108,10 @@ struct BufDesc {
 // Arena slot of one Arrow buffer of one chunk: `alloc` bytes are reserved (exact Arrow size, bitmaps rounded up to
 // whole 64-bit words so a wavefront's ballot store never leaves the slot), `exact` is the Arrow size.  ONE statement of
 // the layout rule, used by the device-side layout kernel (rh_k_layout) and by the host when it exports the buffers.
-RH_HD inline uint64_t buf_bytes(int32_t kind, uint64_t rows, uint64_t data_total, uint64_t* exact) {
+RH_HD inline uint64_t buf_bytes(int32_t kind, uint64_t rows, uint64_t data_total, uint64_t* exact, uint32_t width = 0) {
   uint64_t sz = 0, ex = 0;
   switch (kind) {
+    case BK_FIXW: sz = ex = rows * width; break;
     case BK_BITMAP: sz = (rows + 63) / 64 * 8; ex = (rows + 7) / 8; break;
     case BK_VAL4: sz = ex = rows * 4; break;
     case BK_VAL8: sz = ex = rows * 8; break;
@@ -135,6 +149,7 @@ struct LParams {
   uint64_t* bufsize;         // out [k][nbuf] (allocated bytes)
   unsigned long long* ctrl;  // control words (see above); ctrl[2] receives the arena bytes used
   uint32_t narrow;           // 1: the schema-specialised kernels will run (32-bit in-buffer byte offsets)
+  uint64_t narrow_rows;      // ... which index child row domains below this many rows (2^28, less with wide fixed columns)
 };
 
 // Kernel parameters (one launch = all chunks of one call on one device).

@@ -1,5 +1,6 @@
 // See schema.h.  Host only (no HIP).
 #include "schema.h"
+#include <cmath>
 
 #include <map>
 #include <set>
@@ -107,14 +108,14 @@ struct Parser {
           {"date", AV_DATE, AV_INT, AV_INT},
           {"timestamp-millis", AV_TS_MILLIS, AV_LONG, AV_LONG},
           {"timestamp-micros", AV_TS_MICROS, AV_LONG, AV_LONG},
-          {"time-millis", AV_OTHER_LOGICAL, AV_INT, AV_INT},
-          {"time-micros", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
+          {"time-millis", AV_TIME_MILLIS, AV_INT, AV_INT},
+          {"time-micros", AV_TIME_MICROS, AV_LONG, AV_LONG},
           {"timestamp-nanos", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
           {"local-timestamp-millis", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
           {"local-timestamp-micros", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
           {"local-timestamp-nanos", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
-          {"uuid", AV_OTHER_LOGICAL, AV_STRING, AV_FIXED},
-          {"decimal", AV_OTHER_LOGICAL, AV_BYTES, AV_FIXED},
+          {"uuid", AV_UUID, AV_STRING, AV_FIXED},
+          {"decimal", AV_DECIMAL, AV_BYTES, AV_FIXED},
           {"duration", AV_OTHER_LOGICAL, AV_FIXED, AV_FIXED},
       };
       for (auto& e : table) {
@@ -123,6 +124,23 @@ struct Parser {
         if (base->kind == e.base1 || base->kind == e.base2) {
           auto t = prim(e.out);
           t->logical = e.name;
+          t->size = base->kind == AV_FIXED ? base->size : -1;
+          if (e.out == AV_UUID && base->kind == AV_FIXED && base->size != 16) return base;   // uuid needs 16 bytes
+          if (e.out == AV_DECIMAL) {
+            // precision is required and positive, scale defaults to 0 and must not exceed it, and a fixed base must be
+            // able to hold the precision; anything else keeps the underlying type (apache-avro warns and does the same)
+            const Value* pv = j.get("precision");
+            const Value* sv = j.get("scale");
+            const double pr = pv && pv->is_number() ? pv->num : 0, sc = sv && sv->is_number() ? sv->num : 0;
+            if (!(pr >= 1 && pr == (double)(int64_t)pr && sc >= 0 && sc == (double)(int64_t)sc && sc <= pr)) return base;
+            if (base->kind == AV_FIXED) {
+              // max precision of n bytes: floor(log10(2^(8n-1) - 1))
+              const double maxp = std::floor((8.0 * (double)base->size - 1.0) * 0.30102999566398120);
+              if (pr > maxp) return base;
+            }
+            t->precision = (int)pr;
+            t->scale = (int)sc;
+          }
           return t;
         }
         return base;
@@ -186,6 +204,10 @@ struct Parser {
     if (t == "fixed") {
       auto f = prim(AV_FIXED);
       register_name(j, enclosing, *f);
+      const Value* sz = j.get("size");
+      if (!sz || !sz->is_number() || sz->num < 0 || sz->num != (double)(int64_t)sz->num)
+        throw SchemaError("No `size` in fixed");
+      f->size = (int64_t)sz->num;
       return f;
     }
     return parse_name(t, enclosing);
@@ -210,8 +232,17 @@ bool supported_inner(const AvroType& t, std::string& why) {
       return true;
     case AV_ARRAY: case AV_MAP:
       return supported_inner(*t.items, why);
-    case AV_BYTES: why = "bytes"; return false;
-    case AV_FIXED: why = "fixed"; return false;
+    // beyond the reference's gate (fast_decode.rs:59 sends these to a fallback whose column builder
+    // answers unimplemented!(), complex.rs:414-431); decoded on the GPU from the Avro 1.11 wire rules
+    case AV_BYTES: case AV_TIME_MILLIS: case AV_TIME_MICROS: case AV_UUID:
+      return true;
+    case AV_FIXED:
+      if (t.size > (1 << 20)) { why = "fixed of more than 1 MiB"; return false; }
+      return true;
+    case AV_DECIMAL:
+      if (t.precision > 38) { why = "decimal precision beyond Decimal128 (38 digits)"; return false; }
+      if (t.size > 16) { why = "decimal on a fixed of more than 16 bytes"; return false; }
+      return true;
     case AV_REF: why = "named-type reference " + t.fullname(); return false;
     default: why = t.logical.empty() ? "unsupported type" : t.logical; return false;
   }
@@ -231,6 +262,11 @@ const char* default_field_name(const std::string& fmt) {   // schema_translate.r
   if (fmt == "tsm:") return "timestampmilli";
   if (fmt == "tsu:") return "timestampmicro";
   if (fmt == "u") return "varchar";
+  if (fmt == "z") return "varbinary";
+  if (fmt.rfind("w:", 0) == 0) return "fixedsizebinary";
+  if (fmt.rfind("d:", 0) == 0) return "decimal";
+  if (fmt == "ttm") return "timemilli";
+  if (fmt == "ttu") return "timemicro";
   if (fmt == "+l") return "list";
   if (fmt == "+s") return "struct";
   if (fmt.rfind("+us:", 0) == 0) return "union";
@@ -277,6 +313,12 @@ ArrowField to_field(const AvroType& t, const std::string* name, bool nullable,
     case AV_DATE: f.format = "tdD"; break;
     case AV_TS_MILLIS: f.format = "tsm:"; break;
     case AV_TS_MICROS: f.format = "tsu:"; break;
+    case AV_BYTES: f.format = "z"; break;                                           // schema_translate.rs:58
+    case AV_FIXED: f.format = "w:" + std::to_string(t.size); break;                 // :133
+    case AV_DECIMAL: f.format = "d:" + std::to_string(t.precision) + "," + std::to_string(t.scale); break;   // :134-136
+    case AV_UUID: f.format = "w:16"; break;                                         // :137
+    case AV_TIME_MILLIS: f.format = "ttm"; break;                                   // :139
+    case AV_TIME_MICROS: f.format = "ttu"; break;                                   // :140
     case AV_ARRAY: {                                   // schema_translate.rs:60-65
       f.format = "+l";
       static const std::string item = "item";
@@ -385,6 +427,8 @@ struct Builder {
       case AV_NULL: return 0;
       case AV_FLOAT: return 4;
       case AV_DOUBLE: return 8;
+      case AV_FIXED: return (uint32_t)t.size;
+      case AV_DECIMAL: case AV_UUID: return t.size >= 0 ? (uint32_t)t.size : 1u;
       case AV_RECORD: {
         uint32_t s = 0;
         for (auto& f : t.fields) s += min_bytes(*f.type);
@@ -438,11 +482,41 @@ struct Builder {
   int build(const AvroType& t, bool nullable, bool null_first, Ctx cx) {
     if (cx.nest > kMaxNest) throw SchemaError("schema nesting too deep for the GPU decoder");
     switch (t.kind) {
-      case AV_INT: case AV_DATE: case AV_LONG: case AV_TS_MILLIS: case AV_TS_MICROS:
+      case AV_FIXED: case AV_DECIMAL: case AV_UUID: {
+        int id = new_node(NK_BIN);
+        const int32_t sub = t.kind == AV_FIXED ? BN_FIXED
+                            : t.kind == AV_DECIMAL ? (t.size >= 0 ? BN_DEC_FIXED : BN_DEC_BYTES)
+                            : (t.size >= 0 ? BN_FIXED : BN_UUID_STR);
+        const int32_t wire = t.size >= 0 ? (int32_t)t.size : 0;
+        const int32_t width = t.kind == AV_FIXED ? (int32_t)t.size : 16;
+        {
+          DecNode& n = cs.nodes[id];
+          n.nullable = nullable; n.null_first = null_first; n.dom = cx.dom;
+          n.can_null = nullable || cx.nullfill;
+          n.bin_width = width;
+        }
+        const bool can_null = cs.nodes[id].can_null;
+        int bv = can_null ? new_buf(BK_BITMAP, cx.dom, -1, id) : -1;
+        int bm = new_buf(BK_FIXW, cx.dom, width, id);
+        cs.nodes[id].buf_validity = bv;
+        cs.nodes[id].buf_main = bm;
+        if ((uint32_t)width > cs.max_row_bytes) cs.max_row_bytes = (uint32_t)width;
+        cs.encode_unsupported = "fixed / decimal / uuid";
+        Op o = mk(OP_BIN);
+        o.flags = (nullable ? F_NULLABLE : 0) | (null_first ? F_NULL_FIRST : 0) | (can_null ? F_CAN_NULL : 0);
+        o.dom = cx.dom; o.a = sub; o.b = wire; o.c = width; o.buf0 = bv; o.buf1 = bm; o.node = id;
+        push(o);
+        return id;
+      }
+      case AV_BYTES:
+        cs.encode_unsupported = "bytes";
+        return string_leaf(NK_STRING, nullable, null_first, cx, nullptr);
+      case AV_INT: case AV_DATE: case AV_LONG: case AV_TS_MILLIS: case AV_TS_MICROS: case AV_TIME_MILLIS: case AV_TIME_MICROS:
       case AV_FLOAT: case AV_DOUBLE: case AV_BOOLEAN: {
+        if (t.kind == AV_TIME_MILLIS || t.kind == AV_TIME_MICROS) cs.encode_unsupported = "time-millis / time-micros";
         int id = new_node(NK_FIXED);
         DecNode& n = cs.nodes[id];
-        n.fixed = (t.kind == AV_INT || t.kind == AV_DATE) ? FK_I32
+        n.fixed = (t.kind == AV_INT || t.kind == AV_DATE || t.kind == AV_TIME_MILLIS) ? FK_I32
                   : (t.kind == AV_FLOAT) ? FK_F32
                   : (t.kind == AV_DOUBLE) ? FK_F64
                   : (t.kind == AV_BOOLEAN) ? FK_BOOL : FK_I64;

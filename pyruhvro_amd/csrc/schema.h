@@ -26,7 +26,8 @@ enum AvroKind {
   AV_NULL, AV_BOOLEAN, AV_INT, AV_LONG, AV_FLOAT, AV_DOUBLE, AV_BYTES, AV_STRING,
   AV_RECORD, AV_ENUM, AV_ARRAY, AV_MAP, AV_UNION, AV_FIXED,
   AV_DATE, AV_TS_MILLIS, AV_TS_MICROS,
-  AV_OTHER_LOGICAL,   // time-*, decimal, uuid, duration, ... (outside the direct-decode subset)
+  AV_TIME_MILLIS, AV_TIME_MICROS, AV_DECIMAL, AV_UUID,   // SURVEY 8f N4 (with AV_BYTES / AV_FIXED): GPU decode only
+  AV_OTHER_LOGICAL,   // duration, local-timestamp-*, timestamp-nanos (no Arrow mapping in the reference: schema_translate.rs:144)
   AV_REF,
 };
 
@@ -50,6 +51,8 @@ struct AvroType {
   std::unique_ptr<AvroType> items;       // array items / map values
   std::vector<std::unique_ptr<AvroType>> variants;  // union
   std::string logical;                   // AV_OTHER_LOGICAL: its name (for messages)
+  int64_t size = 0;                      // fixed: bytes | decimal / uuid on a fixed base: its size (-1: bytes / string base)
+  int precision = 0, scale = 0;          // decimal
   std::string fullname() const { return ns.empty() ? name : ns + "." + name; }
 };
 
@@ -66,6 +69,7 @@ struct ArrowField {
 // ---- decoder tree -------------------------------------------------------------
 enum NodeKind {
   NK_FIXED, NK_STRING, NK_ENUM, NK_NULL, NK_RECORD, NK_UNION, NK_LIST, NK_MAP,
+  NK_BIN,       // fixed / decimal / uuid (OP_BIN): validity + a values buffer of `bin_width` bytes per row
 };
 
 struct DecNode {
@@ -84,6 +88,7 @@ struct DecNode {
   int buf_main = -1;          // values / value bits / offsets / type_ids
   int buf_data = -1;          // string bytes
   int counter = -1;           // string byte counter id
+  int bin_width = 0;          // NK_BIN: bytes per row
 };
 
 struct CompiledSchema {
@@ -99,6 +104,8 @@ struct CompiledSchema {
   int ndom = 1;
   int list_depth = 0;
   uint32_t min_record_bytes = 0;
+  uint32_t max_row_bytes = 16;      // widest fixed-width value of one row (bounds the 32-bit in-buffer offsets of the specialised kernels)
+  std::string encode_unsupported;   // non-empty: why rh_encode does not take this schema (N4 types are decode-only)
 };
 
 // Throws SchemaError.  `json` need not be NUL-terminated.

@@ -517,6 +517,101 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   put_validity<EMIT>(c, op, act, valid, row);
 }
 
+// --------------------------------------------------------------------------
+// fixed / decimal / uuid leaves.  The reference translates these schemas to Arrow
+// (schema_translate.rs:133-137: fixed -> FixedSizeBinary(n), decimal -> Decimal128(p, s), uuid -> FixedSizeBinary(16))
+// but never decodes them on its direct path (fast_decode.rs:59), and its Value-tree fallback has no builder for
+// them (complex.rs:414-431): the wire forms below are the Avro 1.11 specification's.  Null slots are zero-filled
+// like every arrow-rs fixed-width builder does.  Not a hot path: byte loops, no fast wire form.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ int hex_nibble(uint32_t ch) {
+  if (ch >= '0' && ch <= '9') return (int)(ch - '0');
+  ch |= 0x20u;
+  if (ch >= 'a' && ch <= 'f') return (int)(ch - 'a' + 10);
+  return -1;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void fill_zero(void* base, uint64_t off, uint32_t n) {
+  uint32_t j = 0;
+  for (; j + 8 <= n; j += 8) st_at<u64u, WIDE>(base, off + j, 0ull);
+  for (; j < n; j++) st_at<uint8_t, WIDE>(base, off + j, (uint8_t)0);
+}
+
+template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+__device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  const bool act = L.live;
+  const bool dec = act && L.pres;
+  const bool has_len = op.a == BN_DEC_BYTES || op.a == BN_UUID_STR;
+  const uint32_t W = (uint32_t)op.c;
+  int64_t v = 0;
+  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, has_len, false, v, true);
+  const bool want = isval && L.live;
+  uint32_t len = (uint32_t)op.b;
+  if (has_len) {
+    const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
+    const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur);
+    RH_REJECT(L, neg, E_NEGLEN);
+    RH_REJECT(L, eob, E_EOB_STR);
+    len = (want && L.live) ? (uint32_t)v : 0u;
+    if (op.a == BN_DEC_BYTES) RH_REJECT(L, want && L.live && len > 16u, E_DECIMAL, (int64_t)len);
+    if (op.a == BN_UUID_STR) RH_REJECT(L, want && L.live && len != 36u && len != 32u, E_UUID);
+  } else {
+    RH_REJECT(L, want && (L.end - L.cur) < len, E_EOB_FIXED);
+  }
+  bool valid = want && L.live;
+  const uint32_t spos = L.cur;
+  // value bits: 16 bytes for decimal / uuid (computed in both passes for uuid: malformed text is an error)
+  uint64_t lo = 0, hi = 0;
+  if (op.a == BN_DEC_BYTES || op.a == BN_DEC_FIXED) {
+    if (EMIT && valid) {
+      const bool negv = len > 0 && (src.ld1(spos) & 0x80u);
+      lo = negv ? ~0ull : 0ull; hi = lo;                       // sign extension of a value shorter than 16 bytes
+      for (uint32_t j = 0; j < len; j++) {
+        const uint64_t b = src.ld1(spos + j);
+        hi = (hi << 8) | (lo >> 56);
+        lo = (lo << 8) | b;
+      }
+    }
+  } else if (op.a == BN_UUID_STR) {
+    bool badtxt = false;
+    if (valid) {
+      uint32_t nn = 0;
+      for (uint32_t j = 0; j < len; j++) {
+        const uint32_t ch = src.ld1(spos + j);
+        if (len == 36u && (j == 8 || j == 13 || j == 18 || j == 23)) { badtxt |= ch != '-'; continue; }
+        const int h = hex_nibble(ch);
+        badtxt |= h < 0;
+        // big-endian byte order of the text; Arrow FixedSizeBinary keeps it: byte i of the value = hex pair i
+        const uint32_t byte = nn >> 1, sh = (nn & 1) ? 0u : 4u;
+        const uint64_t bits = (uint64_t)(h & 15) << (8 * (byte & 7) + sh);
+        if (byte < 8) lo |= bits; else hi |= bits;
+        nn++;
+      }
+      badtxt |= nn != 32u;
+    }
+    RH_REJECT(L, valid && badtxt, E_UUID);
+    valid = valid && L.live;
+  }
+  L.cur += valid ? len : 0u;
+  uint32_t row = 0;
+  if (EMIT) {
+    row = row_of(c, op.dom);
+    if (act && W) {
+      const uint64_t off = (uint64_t)row * W;
+      if (op.a == BN_FIXED) {
+        if (valid) copy_bytes<Ctx::kWide>(c.buf(op.buf1), off, src, spos, len);
+        else fill_zero<Ctx::kWide>(c.buf(op.buf1), off, W);
+      } else {
+        if (!valid) { lo = 0; hi = 0; }
+        st_at<u64u, Ctx::kWide>(c.buf(op.buf1), off, lo);
+        st_at<u64u, Ctx::kWide>(c.buf(op.buf1), off + 8, hi);
+      }
+    }
+  }
+  put_validity<EMIT>(c, op, act, valid, row);
+}
+
 // NullableRecord (482-485 + 595-616): a null record null-fills its children
 template <bool EMIT, bool CAREFUL, class Src, class Ctx>
 __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {

@@ -60,7 +60,7 @@ def assert_identical(a: pa.Array, b: pa.Array, path: str = "") -> None:
             assert np.array_equal(_bits(ba[0], n), _bits(bb[0], n)), f"{path}: validity bits differ"
     if pa.types.is_boolean(t):
         assert np.array_equal(_bits(ba[1], n), _bits(bb[1], n)), f"{path}: boolean values differ"
-    elif pa.types.is_string(t):
+    elif pa.types.is_string(t) or pa.types.is_binary(t):
         assert _bytes(ba[1], 4 * (n + 1)) == _bytes(bb[1], 4 * (n + 1)), f"{path}: string offsets differ"
         last = int(_bytes(ba[1], 4 * (n + 1)).i32()[-1])
         assert _bytes(ba[2], last) == _bytes(bb[2], last), f"{path}: string data differ"

@@ -31,6 +31,8 @@ WORKER = textwrap.dedent("""
     rank, world, wall, per_rank, agg, cfg = bench.run(args, make_step, backend="gloo")
     print("RESULT " + json.dumps({"rank": rank, "world": world, "wall": wall, "per_rank": per_rank, "agg": agg,
                                   "shard": bench.run.info["shard"]}))
+    import torch.distributed as dist
+    dist.destroy_process_group()
 """)
 
 # the same two ranks with a REAL decode: each rank generates only ITS rows of the seeded list, decodes them on
@@ -66,6 +68,8 @@ REAL_WORKER = textwrap.dedent("""
     args = bench.parse_args(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "full1m", "--records", str(N)])
     rank, world, wall, per_rank, agg, cfg = bench.run(args, make_step, backend="gloo")
     print("RESULT " + json.dumps({"rank": rank, "world": world, "per_rank": per_rank, "agg": agg, "checked": checked}))
+    import torch.distributed as dist
+    dist.destroy_process_group()
 """) % (ROOT, ROOT)
 
 

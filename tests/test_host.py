@@ -59,10 +59,10 @@ def test_arrow_schema_nesting_cases_and_metadata():
 BAD_SCHEMAS = [
     ("not json", "Failed to parse schema"),
     ('"string"', "record"),
-    ('{"type":"record","name":"x","fields":[{"name":"a","type":"bytes"}]}', "bytes"),
-    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f","size":4}}]}', "fixed"),
-    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"int","logicalType":"time-millis"}}]}', "time-millis"),
-    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"string","logicalType":"uuid"}}]}', "uuid"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f","size":12,"logicalType":"duration"}}]}', "duration"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"long","logicalType":"local-timestamp-millis"}}]}', "local-timestamp-millis"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"long","logicalType":"timestamp-nanos"}}]}', "timestamp-nanos"),
+    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f"}}]}', "size"),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":"nosuchtype"}]}', "Unknown type"),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"record","name":"y","fields":[]}},{"name":"b","type":"y"}]}', ""),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":["null",{"type":"map","values":"int"}]}]}', "Map support"),

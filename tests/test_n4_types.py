@@ -1,0 +1,192 @@
+"""bytes, fixed, decimal, uuid, time-millis, time-micros on the GPU decode path.
+
+The reference TRANSLATES these schemas to Arrow (schema_translate.rs:58,133-140 -- restated in the oracle and matched
+by the product, tested here) but never DECODES them: its direct path rejects them (fast_decode.rs:59) and the
+Value-tree fallback it falls back to has no column builder for the Arrow types it just chose (complex.rs:414-431:
+unimplemented!()).  So there is no reference behaviour to pin: the expected values below are known-answer vectors
+worked out from the Avro 1.11 specification, the oracle restates that specification (py_walker `extended=True`), and
+DESIGN.md marks parity for these types "specification-pinned, unpinned by the reference"."""
+import datetime
+import decimal
+import json
+
+import pyarrow as pa
+import pytest
+
+from arrow_compare import assert_batches_identical
+from avrogen.encoder import Branch, Unscaled, UuidText, to_datum, zigzag
+from oracle import avro_schema as S
+from oracle import py_walker
+
+import pyruhvro_amd as P
+from pyruhvro_amd import cabi
+
+F = lambda name, size, **kw: dict({"type": "fixed", "name": name, "size": size}, **kw)      # noqa: E731
+SCHEMA = json.dumps({"type": "record", "name": "N4", "fields": [
+    {"name": "b", "type": "bytes"},
+    {"name": "nb", "type": ["null", "bytes"]},
+    {"name": "f", "type": F("F5", 5)},
+    {"name": "nf", "type": [F("F3", 3), "null"]},
+    {"name": "d", "type": {"type": "bytes", "logicalType": "decimal", "precision": 10, "scale": 2}},
+    {"name": "nd", "type": ["null", {"type": "bytes", "logicalType": "decimal", "precision": 38, "scale": 0}]},
+    {"name": "df", "type": F("D8", 8, logicalType="decimal", precision=18, scale=4)},
+    {"name": "u", "type": {"type": "string", "logicalType": "uuid"}},
+    {"name": "nu", "type": ["null", F("U16", 16, logicalType="uuid")]},
+    {"name": "tm", "type": {"type": "int", "logicalType": "time-millis"}},
+    {"name": "tu", "type": ["null", {"type": "long", "logicalType": "time-micros"}]},
+    {"name": "arr", "type": {"type": "array", "items": F("F2", 2)}},
+    {"name": "m", "type": {"type": "map", "values": ["null", {"type": "bytes", "logicalType": "decimal", "precision": 5, "scale": 1}]}},
+    {"name": "un", "type": ["null", "bytes", F("F4", 4), "int", {"type": "string", "logicalType": "uuid"}]},
+    {"name": "rec", "type": ["null", {"type": "record", "name": "In", "fields": [
+        {"name": "x", "type": F("F1", 1)}, {"name": "y", "type": {"type": "int", "logicalType": "time-millis"}},
+        {"name": "z", "type": {"type": "bytes", "logicalType": "decimal", "precision": 4, "scale": 4}}]}]},
+    {"name": "tail", "type": "string"},
+]})
+UUID = "550e8400-e29b-41d4-a716-446655440000"
+UUID_BYTES = bytes.fromhex(UUID.replace("-", ""))
+
+
+def _rows(n):
+    out = []
+    for i in range(n):
+        out.append({
+            "b": bytes(range(i % 40)), "nb": None if i % 3 == 0 else b"\xff" * (i % 5),
+            "f": bytes([i % 256] * 5), "nf": None if i % 2 else b"xyz",
+            "d": Unscaled(1234 - 77 * i), "nd": None if i % 4 == 1 else Unscaled((-1) ** i * (10 ** (i % 36)) + i, pad=i % 3 if i % 36 < 28 else 0),
+            "df": Unscaled(-5 * i), "u": UuidText(UUID if i % 2 else UUID.replace("-", "").upper()),
+            "nu": None if i % 5 == 0 else UuidText(UUID_BYTES[::-1]),
+            "tm": (i * 7919) % 86_400_000, "tu": None if i % 7 == 0 else i * 1_000_003,
+            "arr": [bytes([i % 256, j]) for j in range(i % 4)],
+            "m": [(f"k{j}", None if (i + j) % 3 == 0 else Unscaled(j - i)) for j in range(i % 3)],
+            "un": [None, b"bytes!" * (i % 3), Branch(2, b"FOUR"), i, Branch(4, UuidText(UUID))][i % 5],
+            "rec": None if i % 3 == 2 else {"x": bytes([i % 256]), "y": i, "z": Unscaled(i % 9999)},
+            "tail": f"row-{i}",
+        })
+    return out
+
+
+def _records(n):
+    sc = S.parse_schema(SCHEMA)
+    return [to_datum(sc, r) for r in _rows(n)]
+
+
+# ---------------------------------------------------------------------------------------------------- CPU
+def test_reference_gate_rejects_what_the_gpu_path_now_accepts():
+    for body in ('"bytes"', json.dumps(F("f", 4)), '{"type":"int","logicalType":"time-millis"}',
+                 '{"type":"long","logicalType":"time-micros"}', '{"type":"string","logicalType":"uuid"}',
+                 '{"type":"bytes","logicalType":"decimal","precision":9,"scale":2}'):
+        js = '{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}' % body
+        avro = S.parse_schema(js)
+        assert not S.is_supported(avro) and S.is_supported_extended(avro)        # fast_decode.rs:59 vs N4
+        with pytest.raises(ValueError):
+            S.build_tree(avro)
+        assert P.arrow_schema(js).equals(S.to_arrow_schema(avro), check_metadata=True)   # schema_translate.rs:58,133-140
+
+
+def test_arrow_translation_matches_the_oracle_and_the_reference_type_map():
+    got = P.arrow_schema(SCHEMA)
+    assert got.equals(S.to_arrow_schema(S.parse_schema(SCHEMA)), check_metadata=True)
+    t = {f.name: f.type for f in got}
+    assert t["b"] == pa.binary() and t["f"] == pa.binary(5) and t["d"] == pa.decimal128(10, 2) and t["df"] == pa.decimal128(18, 4)
+    assert t["u"] == pa.binary(16) and t["nu"] == pa.binary(16) and t["tm"] == pa.time32("ms") and t["tu"] == pa.time64("us")
+    assert [c.name for c in t["un"]] == ["null", "varbinary", "fixedsizebinary", "int", "fixedsizebinary"]       # default_field_name
+    # decimal attributes that do not make a decimal keep the underlying type (apache-avro warns): precision 0 / scale > precision /
+    # a fixed too small for the precision; uuid on a fixed that is not 16 bytes
+    for body, want in (('{"type":"bytes","logicalType":"decimal","precision":0}', pa.binary()),
+                       ('{"type":"bytes","logicalType":"decimal","precision":3,"scale":4}', pa.binary()),
+                       (json.dumps(F("q", 2, logicalType="decimal", precision=5)), pa.binary(2)),
+                       (json.dumps(F("q", 8, logicalType="uuid")), pa.binary(8))):
+        js = '{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}' % body
+        assert P.arrow_schema(js).field("a").type == want == S.to_arrow_schema(S.parse_schema(js)).field("a").type
+    for body in ('{"type":"bytes","logicalType":"decimal","precision":39}', json.dumps(F("q", 17, logicalType="decimal", precision=39))):
+        with pytest.raises(ValueError):          # beyond Decimal128
+            P.arrow_schema('{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}' % body)
+
+
+def test_specification_known_answers_pin_the_oracle():
+    """Hand-assembled datums (Avro 1.11: bytes = length + raw; fixed = raw; decimal = big-endian two's complement of the
+    unscaled value; uuid = RFC 4122 text) against literal expected values."""
+    js = json.dumps({"type": "record", "name": "K", "fields": [
+        {"name": "d", "type": {"type": "bytes", "logicalType": "decimal", "precision": 10, "scale": 2}},
+        {"name": "df", "type": F("D2", 2, logicalType="decimal", precision=4, scale=1)},
+        {"name": "b", "type": "bytes"}, {"name": "f", "type": F("F3", 3)},
+        {"name": "u", "type": {"type": "string", "logicalType": "uuid"}},
+        {"name": "tm", "type": {"type": "int", "logicalType": "time-millis"}},
+        {"name": "tu", "type": {"type": "long", "logicalType": "time-micros"}}]})
+    recs = [
+        bytes.fromhex("04" "04d2") + bytes.fromhex("ff85") + bytes.fromhex("06" "00ff10") + b"abc" + bytes([72]) + UUID.encode()
+        + zigzag(3_723_004) + zigzag(86_399_999_999),
+        bytes.fromhex("02" "ff") + bytes.fromhex("0000") + bytes.fromhex("00") + b"\x00\x01\x02" + bytes([64]) + UUID.replace("-", "").encode()
+        + zigzag(0) + zigzag(1),
+    ]
+    rows = py_walker.decode(recs, js, extended=True).to_pylist()
+    assert rows[0] == {"d": decimal.Decimal("12.34"), "df": decimal.Decimal("-12.3"), "b": b"\x00\xff\x10", "f": b"abc", "u": UUID_BYTES,
+                       "tm": datetime.time(1, 2, 3, 4000), "tu": datetime.time(23, 59, 59, 999999)}
+    assert rows[1] == {"d": decimal.Decimal("-0.01"), "df": decimal.Decimal("0.0"), "b": b"", "f": b"\x00\x01\x02", "u": UUID_BYTES,
+                       "tm": datetime.time(0, 0), "tu": datetime.time(0, 0, 0, 1)}
+    for bad, msg in ((bytes.fromhex("22") + b"\x01" * 17, "decimal value of 17 bytes does not fit Decimal128"),
+                     (bytes.fromhex("02" "01" "00"), "unexpected end of buffer (fixed)")):
+        with pytest.raises(ValueError, match=msg.replace("(", r"\(").replace(")", r"\)")):
+            py_walker.decode([bad], js, extended=True)
+
+
+def test_encode_direction_says_no_clearly():
+    rb = pa.RecordBatch.from_arrays([pa.array([b"x"], pa.binary())], names=["a"])
+    with pytest.raises(ValueError, match="outside the GPU encode path"):
+        P.serialize_record_batch(rb, '{"type":"record","name":"x","fields":[{"name":"a","type":"bytes"}]}', 1)
+
+
+# ---------------------------------------------------------------------------------------------------- GPU
+KERNELS = {"generic": cabi.KERNEL_GENERIC, "specialized": cabi.KERNEL_SPECIALIZED}
+
+
+@pytest.fixture(params=sorted(KERNELS))
+def kernel(request):
+    old = P.set_kernel_mode(request.param)
+    yield KERNELS[request.param]
+    P.set_kernel_mode(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1, 1), (64, 1), (257, 3), (1500, 8)])
+def test_gpu_matches_the_specification_oracle(n, k, kernel):
+    recs = _records(n)
+    whole = py_walker.decode(recs, SCHEMA, extended=True)
+    got = P.deserialize_array_threaded(recs, SCHEMA, k)
+    kk = min(k, n)
+    sz = n // kk
+    assert [b.num_rows for b in got] == [sz] * (kk - 1) + [n - (kk - 1) * sz]
+    for i, g in enumerate(got):
+        g.validate(full=True)
+        lo = i * sz
+        exp = py_walker.decode(recs[lo: lo + g.num_rows], SCHEMA, extended=True)
+        assert_batches_identical(g, exp)
+    assert pa.Table.from_batches(got).to_pylist() == whole.to_pylist()
+    old = P.set_devices([0, 0, 0])
+    try:
+        for g, e in zip(P.deserialize_array_threaded(recs, SCHEMA, k), got):
+            assert_batches_identical(g, e)
+    finally:
+        P.set_devices(old)
+
+
+@pytest.mark.gpu
+def test_gpu_error_texts(kernel):
+    js = json.dumps({"type": "record", "name": "E", "fields": [
+        {"name": "f", "type": F("F6", 6)}, {"name": "d", "type": {"type": "bytes", "logicalType": "decimal", "precision": 9, "scale": 0}},
+        {"name": "u", "type": ["null", {"type": "string", "logicalType": "uuid"}]}]})
+    good = b"sixsix" + bytes.fromhex("02" "07") + b"\x02" + bytes([72]) + UUID.encode()
+    assert P.deserialize_array([good] * 3, js).to_pylist()[2] == {"f": b"sixsix", "d": decimal.Decimal(7), "u": UUID_BYTES}
+    for bad, msg in ((b"six", "unexpected end of buffer (fixed)"),
+                     (b"sixsix" + bytes.fromhex("22") + b"\x01" * 17 + b"\x00", "decimal value of 17 bytes does not fit Decimal128"),
+                     (b"sixsix" + bytes.fromhex("02" "07") + b"\x02" + bytes([72]) + UUID.replace("e", "g", 1).encode(), "invalid uuid string"),
+                     (b"sixsix" + bytes.fromhex("02" "07") + b"\x02" + bytes([70]) + UUID[:35].encode(), "invalid uuid string"),
+                     (b"sixsix" + bytes.fromhex("02" "07") + b"\x02" + bytes([72]) + UUID.replace("-", "+").encode(), "invalid uuid string"),
+                     (b"sixsix" + bytes.fromhex("0a" "07"), "unexpected end of buffer (string)")):
+        for recs in ([bad], [good] * 70 + [bad] + [good] * 5):
+            with pytest.raises(ValueError) as ei:
+                P.deserialize_array_threaded(recs, js, 2)
+            assert str(ei.value) == msg
+            with pytest.raises(ValueError) as eo:
+                py_walker.decode(recs, js, extended=True)
+            assert str(eo.value) == msg

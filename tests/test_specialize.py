@@ -47,13 +47,16 @@ def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
     assert loop.index("e_list_next") < loop.index("e_span_load") < loop.index("e_string_put")   # list items: loads per iteration
     # enum symbols are folded into the kernel as (length, masked dword) compares
     assert "n == 1u && (a.x & 0x000000ffu) == 0x00000041u" in src
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError):      # bytes decodes on the GPU but has no encode kernels
         cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":"bytes"}]}')
+    with pytest.raises(ValueError):
+        cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"fixed","name":"d","size":12,"logicalType":"duration"}}]}')
 
 
 def test_unsupported_schema_has_no_kernel():
     with pytest.raises(ValueError):
-        cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":"bytes"}]}')
+        cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"long","logicalType":"local-timestamp-micros"}}]}')
+    assert "h_bin<EMIT, CAREFUL>" in cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"fixed","name":"f","size":7}}]}')
 
 
 STAGED_VARIANTS = "SOME_EXPERIMENT,OTHER_1"
