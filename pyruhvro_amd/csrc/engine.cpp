@@ -10,6 +10,14 @@
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
 
+// <hip/hip_ext.h> needs the HIP compiler; this translation unit is also built by g++ (sanitizer build).  The one
+// function used from it, as declared there:
+extern "C" hipError_t hipExtModuleLaunchKernel(hipFunction_t f, uint32_t globalWorkSizeX, uint32_t globalWorkSizeY,
+                                               uint32_t globalWorkSizeZ, uint32_t localWorkSizeX, uint32_t localWorkSizeY,
+                                               uint32_t localWorkSizeZ, size_t sharedMemBytes, hipStream_t hStream,
+                                               void** kernelParams, void** extra, hipEvent_t startEvent,
+                                               hipEvent_t stopEvent, uint32_t flags);
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -31,12 +39,14 @@
 #include "encode.h"
 
 extern "C" {
-int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream);
-int rh_launch_scan(const rh::KParams* P, void* stream);
+// start / stop: optional hipEvent_t that receive the kernel's own begin / end timestamps (hipExtLaunchKernelGGL): no
+// separate marker packets in the stream, so timing a call costs it almost nothing
+int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
+int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
 int rh_launch_layout(const rh::LParams* L, void* stream);
-int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream);
+int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
 // Arrow -> Avro kernels (encode.hip)
@@ -290,10 +300,13 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile, bool
   return table[device];
 }
 
-int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream) {
+int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream,
+                  hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
   rh::KParams copy = P;
   void* args[] = {&copy};
-  return (int)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, stream, args, nullptr);
+  if (!start && !stop) return (int)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, stream, args, nullptr);
+  // the kernel's own start / stop timestamps land in the events (global size is in work-items here)
+  return (int)hipExtModuleLaunchKernel(f, grid * block, 1, 1, block, 1, 1, lds, stream, args, nullptr, start, stop, 0);
 }
 
 std::string format_error(const rh::ErrInfo& e) {
@@ -347,6 +360,28 @@ struct Range {
   ~Range() { if (on) Roctx::get().pop(); }
   Range(const Range&) = delete;
   Range& operator=(const Range&) = delete;
+};
+
+// Host-side phase times of one call (RUHVRO_HIP_HOSTPROF=1 -> one stderr line per decode_device call): where the
+// microseconds between the kernels go on small inputs.
+struct HostProf {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  std::string line;
+  HostProf() {
+    static const bool e = [] { const char* v = std::getenv("RUHVRO_HIP_HOSTPROF"); return v && *v && *v != '0'; }();
+    on = e;
+    if (on) t0 = std::chrono::steady_clock::now();
+  }
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t = std::chrono::steady_clock::now();
+    char buf[64];
+    std::snprintf(buf, sizeof buf, " %s=%.1f", what, std::chrono::duration<double, std::micro>(t - t0).count());
+    line += buf;
+    t0 = t;
+  }
+  ~HostProf() { if (on) std::fprintf(stderr, "[ruhvro_hip hostprof us]%s\n", line.c_str()); }
 };
 
 rh_opts default_opts() {
@@ -557,11 +592,12 @@ void export_field(const rh::ArrowField& f, ArrowSchema* out) {
 // the launch sequence
 // ---------------------------------------------------------------------------
 struct Events {
-  hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool on = false;
   void init() { for (auto& x : e) HIPCHK(hipEventCreate(&x)); on = true; }
   ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
   void rec(int i, hipStream_t s) { if (on) HIPCHK(hipEventRecord(e[i], s)); }
+  hipEvent_t at(int i) const { return on ? e[i] : nullptr; }
   float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
 };
 
@@ -593,6 +629,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
                                       uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo) {
   const CompiledSchema& cs = *s->cs;
   Range rk("ruhvro_hip:decode_device (k_size, k_scan, k_layout, k_init, k_emit)");
+  HostProf hp;
   int device = 0;
   if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
   else HIPCHK(hipGetDevice(&device));
@@ -662,9 +699,12 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
   const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
   const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 2ull * K * nblocks * tile : 0), kAlign);
+  hp.mark("setup");
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
+  hp.mark("leases");
   HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
+  hp.mark("memset");
 
   rh::KParams P;
   std::memset(&P, 0, sizeof P);
@@ -706,6 +746,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
   Events ev;
   if (stats) ev.init();
+  hp.mark("events");
   auto check_bad = [&](const uint8_t* h) {
     unsigned long long fb = *(const unsigned long long*)h;
     if (!fb) return;
@@ -769,13 +810,15 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   auto launch_tail = [&](bool offsets_done) {     // k_init + k_emit through the device tables at dtab
     if (nbuf > 0 && (child_bitmaps || !offsets_done) &&
         rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
-    ev.rec(3, stream);
     if (n > 0) {
       emit_lds = lds_bytes;
-      if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream) : rh_launch_emit(&P, emit_lds, stream))
+      if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4))
+             : rh_launch_emit(&P, emit_lds, stream, ev.at(3), ev.at(4)))
         throw HipError("k_emit launch failed");
+    } else {
+      ev.rec(3, stream);
+      ev.rec(4, stream);
     }
-    ev.rec(4, stream);
   };
   auto exact_tail = [&]() {      // totals are on the host: exactly sized arena, tables from the host
     layout_host();
@@ -799,19 +842,19 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   static const bool two_sync = [] { const char* e = std::getenv("RUHVRO_HIP_TWO_SYNC"); return e && *e && *e != '0'; }();
   const double ratio = s->arena_ratio.load();
   const bool fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
-  ev.rec(0, stream);
-  if (n > 0 && K > 0) {
-    if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream) : rh_launch_size(&P, lds_bytes, stream))
+  // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
+  // e3..e4 = k_emit
+  const bool timed_size = n > 0 && K > 0;
+  if (timed_size) {
+    if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
+           : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
       throw HipError("k_size launch failed");
-    ev.rec(1, stream);
-    if (rh_launch_scan(&P, stream)) throw HipError("k_scan launch failed");
-    ev.rec(2, stream);
+    if (rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
   } else {
     // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
     if (sk && n > 0) HIPCHK(hipMemsetAsync(ws.ptr() + o_flag, 0x02, 4ull * nblocks, stream));
-    ev.rec(1, stream);
-    ev.rec(2, stream);
   }
+  hp.mark("size+scan_launch");
   const double basis = (double)payload + 64.0 * (double)n;
   if (fused) {
     const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
@@ -824,8 +867,11 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     LP.narrow_rows = narrow_rows;
     if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
     launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
+    hp.mark("layout+emit_launch");
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+    hp.mark("d2h_enqueue");
     HIPCHK(hipStreamSynchronize(stream));
+    hp.mark("sync");
     check_bad(hctrl.ptr());
     if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
     const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
@@ -852,6 +898,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   }
   r.nullcount.assign((size_t)nnodes * k, 0);
   std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
+  hp.mark("host_layout");
 
   if (profile && sk) {
     unsigned long long hr[64 * 32], h[32] = {0};
@@ -872,9 +919,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     stats->output_bytes = exact;
     stats->chunks = k;
     stats->blocks = nblocks;
-    stats->size_kernel_ms = ev.ms(0, 1);
-    stats->scan_kernel_ms = ev.ms(1, 2);
-    stats->emit_kernel_ms = ev.ms(3, 4);
+    stats->size_kernel_ms = timed_size ? ev.ms(0, 1) : 0.f;
+    stats->scan_kernel_ms = timed_size ? ev.ms(5, 2) : 0.f;
+    stats->emit_kernel_ms = n > 0 ? ev.ms(3, 4) : 0.f;
     stats->specialized = sk ? 1 : 0;
     stats->lds_bytes = emit_lds;
   }
@@ -1781,7 +1828,7 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   if (n > 0) {
     if (launch(false, lds)) throw HipError("e_size launch failed");
     ev.rec(1, stream);
-    if (rh_launch_scan(&SP, stream)) throw HipError("k_scan launch failed");
+    if (rh_launch_scan(&SP, stream, nullptr, nullptr)) throw HipError("k_scan launch failed");
     ev.rec(2, stream);
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));

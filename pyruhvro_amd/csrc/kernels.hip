@@ -21,6 +21,7 @@
 //           bytes with per-lane 8-byte stores at the scanned byte offsets.
 // HBM-bound byte shuffling: no MFMA anywhere.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "kernel_common.h"
@@ -350,12 +351,14 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
 // --------------------------------------------------------------------------
 // launchers (called from engine.cpp; plain C linkage, HIP types stay in here)
 // --------------------------------------------------------------------------
-extern "C" int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream) {
-  hipLaunchKernelGGL(rh::rh_k_size, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, *P);
+extern "C" int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
+  hipExtLaunchKernelGGL(rh::rh_k_size, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
+                        (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
-extern "C" int rh_launch_scan(const rh::KParams* P, void* stream) {
-  hipLaunchKernelGGL(rh::rh_k_scan, dim3((uint32_t)P->K * P->k), dim3(rh::kBlock), 0, (hipStream_t)stream, *P);
+extern "C" int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop) {
+  hipExtLaunchKernelGGL(rh::rh_k_scan, dim3((uint32_t)P->K * P->k), dim3(rh::kBlock), 0, (hipStream_t)stream, (hipEvent_t)start,
+                        (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf,
@@ -368,8 +371,9 @@ extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
   hipLaunchKernelGGL(rh::rh_k_layout, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, *L);
   return (int)hipGetLastError();
 }
-extern "C" int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream) {
-  hipLaunchKernelGGL(rh::rh_k_emit, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, *P);
+extern "C" int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
+  hipExtLaunchKernelGGL(rh::rh_k_emit, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
+                        (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_set_max_lds(uint32_t bytes) {
