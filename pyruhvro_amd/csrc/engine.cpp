@@ -724,7 +724,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)
-  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
+  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
   const uint64_t payload = geo ? geo->payload_bytes : data_len;
   const uint64_t avg = n ? payload / n + 1 : 16;
   uint64_t win = align_up(avg * tile * 115 / 100 + 2048 * tile / rh::kBlock, 16);
@@ -1916,5 +1916,7 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
 extern "C" int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema, uint64_t num_chunks,
                          const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !batch || !batch_schema || !out_chunks) return RH_ERR_ARGUMENT;
+  // the caller only "provides room": zero it so that every failure path can tell produced chunks from garbage
+  std::memset(out_chunks, 0, sizeof(ArrowArray) * rh_clamp_chunks(batch->length < 0 ? 0 : (uint64_t)batch->length, num_chunks));
   return guarded(err, [&] { return encode_impl(const_cast<rh_schema*>(s), batch, batch_schema, num_chunks, opts, out_chunks, out_k, stats); });
 }

@@ -54,6 +54,11 @@ struct ICtx {
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
   }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
+  // child-domain bitmaps: one fire-and-forget atomic per bit on zeroed words (k_init).  The specialised kernels build
+  // these words in LDS instead (spec_body.h SCtx::set_bit); this form is the fallback for rows beyond their LDS words.
+  __device__ __forceinline__ void set_bit(int buf, int /*dom*/, uint32_t row) const {
+    atomic_or_global(this->buf(buf), row >> 5, 1u << (row & 31));
+  }
 };
 
 // --------------------------------------------------------------------------

@@ -179,7 +179,7 @@ struct KParams {
   uint32_t* blocksum;        // [K][nblocks]
   uint32_t* blockbase;       // [K][nblocks] chunk-relative exclusive prefix
   uint64_t* totals;          // [K][k]
-  unsigned long long* first_bad;  // lowest failing record index, ~0 if none
+  unsigned long long* first_bad;  // control words (see LayoutFlag): [0] = ~(lowest failing record index), 0 if none (atomicMax)
   ErrInfo* errinfo;          // [nblocks]
   void* const* bufptr;       // [k][nbuf]
   uint32_t* nullcount;       // [nnodes][k]

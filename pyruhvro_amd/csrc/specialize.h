@@ -24,8 +24,14 @@ std::vector<char> compile_kernel(const std::string& source, std::string& log);
 std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache, bool encode = false);
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
-inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw) {
-  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4;
+inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw, int nbm) {
+  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * 64);
+}
+// child-domain bitmap buffers of a schema (validity / boolean values of rows that do not line up with lanes)
+inline int child_bitmap_count(const CompiledSchema& cs) {
+  int n = 0;
+  for (const BufDesc& d : cs.bufs) n += (d.kind == BK_BITMAP && d.dom != 0) ? 1 : 0;
+  return n;
 }
 
 }  // namespace rh

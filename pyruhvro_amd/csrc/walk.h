@@ -392,6 +392,7 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
 //   uint32_t gbase(int id)      chunk-relative base of this workgroup for counter id
 //   void add_nulls_wave(int node, uint32_t n)   n is wave-uniform (called by every lane)
 //   void add_nulls_lane(int node)               one null row of this lane (child domains)
+//   void set_bit(int buf, int dom, uint32_t row) set one bit of a CHILD-domain bitmap (rows there do not line up with lanes)
 //   lrow, lane, wave_live, sym_off, sym_data
 // --------------------------------------------------------------------------
 template <class Ctx>
@@ -410,7 +411,7 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
     if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf0), c.lrow >> 6, m);
     c.add_nulls_wave(op.node, (uint32_t)__popcll(nm));
   } else if (act) {
-    if (valid) atomic_or_global(c.buf(op.buf0), row >> 5, 1u << (row & 31));
+    if (valid) c.set_bit(op.buf0, op.dom, row);
     else c.add_nulls_lane(op.node);
   }
 }
@@ -454,7 +455,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
         const uint64_t m = __ballot(bits != 0);
         if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf1), c.lrow >> 6, m);
       } else if (act && bits) {
-        atomic_or_global(c.buf(op.buf1), row >> 5, 1u << (row & 31));
+        c.set_bit(op.buf1, op.dom, row);
       }
     } else if (act) {
       if (op.a == FK_I32 || op.a == FK_F32) st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row, (uint32_t)bits);
