@@ -54,6 +54,10 @@ struct ICtx {
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
   }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
+  // domain-0 bitmaps: rows == lanes, one 64-bit store per wavefront
+  __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
+    if (lane == 0 && wave_live) st_global<uint64_t, kWide>(this->buf(buf), lrow >> 6, m);
+  }
   // child-domain bitmaps: one fire-and-forget atomic per bit on zeroed words (k_init).  The specialised kernels build
   // these words in LDS instead (spec_body.h SCtx::set_bit); this form is the fallback for rows beyond their LDS words.
   __device__ __forceinline__ void set_bit(int buf, int /*dom*/, uint32_t row) const {

@@ -91,6 +91,11 @@ struct SCtx {
   // instead of one global atomic per BIT, which serialises at the L2 when 32 lanes hit one dword (tools/storecost.hip:
   // ~1800 cycles per wave instruction; measured on a schema with nullable list items and map values, 2M records:
   // k_emit 0.354 -> 0.113 ms, profiles/r02f_child_bitmap_ab.jsonl).  Rows beyond the LDS words (a tile with > ~2000 child rows) take the global form.
+  // domain-0 bitmaps: rows == lanes, one ballot and one 64-bit store per wavefront and field.  (Collecting the ~15 words
+  // of a wave in one VGPR with v_writelane and storing them once was measured: no gain, profiles/r02g_variants_ab.txt.)
+  __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
+    if (lane == 0 && wave_live) st_global<uint64_t, kWide>(this->buf(buf), lrow >> 6, m);
+  }
   uint32_t* bm;                                       // LDS [NBM][kBmWords]
   __device__ __forceinline__ void set_bit(int buf, int dom, uint32_t row) const {
     if constexpr (S::NBM > 0) {

@@ -393,6 +393,7 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
 //   void add_nulls_wave(int node, uint32_t n)   n is wave-uniform (called by every lane)
 //   void add_nulls_lane(int node)               one null row of this lane (child domains)
 //   void set_bit(int buf, int dom, uint32_t row) set one bit of a CHILD-domain bitmap (rows there do not line up with lanes)
+//   void put_word0(int buf, uint64_t m)          this wavefront's 64 bits of a DOMAIN-0 bitmap (rows == lanes: a ballot)
 //   lrow, lane, wave_live, sym_off, sym_data
 // --------------------------------------------------------------------------
 template <class Ctx>
@@ -408,7 +409,7 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
   if (op.dom == 0) {   // rows == lanes: one ballot, one 64-bit store per wavefront
     const uint64_t m = __ballot(valid);
     const uint64_t nm = __ballot(act && !valid);
-    if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf0), c.lrow >> 6, m);
+    c.put_word0(op.buf0, m);
     c.add_nulls_wave(op.node, (uint32_t)__popcll(nm));
   } else if (act) {
     if (valid) c.set_bit(op.buf0, op.dom, row);
@@ -453,7 +454,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     if (op.a == FK_BOOL) {
       if (op.dom == 0) {
         const uint64_t m = __ballot(bits != 0);
-        if (c.lane == 0 && c.wave_live) st_global<uint64_t, Ctx::kWide>(c.buf(op.buf1), c.lrow >> 6, m);
+        c.put_word0(op.buf1, m);
       } else if (act && bits) {
         c.set_bit(op.buf1, op.dom, row);
       }
