@@ -24,8 +24,14 @@ struct EParams {
   void* const* outptr;          // [k][2]: offsets (i32[rows+1]), data
   uint32_t* rowlen;             // [nblocks*256] encoded length of every row: written by rh_e_size, read by rh_e_emit
   uint32_t win_bytes;           // rh_e_emit: LDS bytes of the output staging window (0 = always store straight to HBM)
+  uint32_t stage_bytes;         // rh_espec_emit: LDS bytes behind the window for the waves' string staging areas (0 = none)
   unsigned long long* first_bad;
   ErrInfo* errinfo;             // [nblocks]
+  unsigned long long* prof;     // [64][32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
 };
+
+// Per-wave LDS area through which rh_espec_emit transposes the string bytes of 64 consecutive rows (encode_walk.h
+// e_string_cofetch): kStageBytes of column data + slack for the 36-byte reads of the last string.
+constexpr uint32_t kStageBytes = 1024, kStageStride = 1088;
 
 }  // namespace rh

@@ -21,6 +21,7 @@ struct ECtx {
   uint32_t* remv;       // LDS [depth][256] items left in the current list
   RH_GLOBAL uint8_t* out;   // emit, direct form: this row's first output byte in HBM
   RH_LDS uint8_t* lout;     // emit, staged form: this row's first output byte in the LDS window
+  RH_LDS uint8_t* stage;    // unused by the interpreter (the specialised kernels' string staging area)
   uint32_t tid;
   __device__ __forceinline__ uint32_t& row(int dom) const { return idx[dom * kBlock + tid]; }
   __device__ __forceinline__ uint32_t& remaining(int d) const { return remv[d * kBlock + tid]; }

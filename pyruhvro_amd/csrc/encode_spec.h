@@ -34,6 +34,7 @@ struct ESCtx {
   const uint8_t* sym_data;
   RH_GLOBAL uint8_t* out;
   RH_LDS uint8_t* lout;
+  RH_LDS uint8_t* stage;    // this wave's string staging area (e_string_cofetch), null = none
   __device__ __forceinline__ uint32_t row(int dom) const {
     uint32_t r = 0;
     e_static_for<0, ND>([&](auto i) { if (decltype(i)::value == dom) r = rowv[decltype(i)::value]; });
@@ -65,7 +66,7 @@ struct ESpecW {
     c.rowv[0] = (uint32_t)(r0 < P.n ? r0 : P.n - 1);          // every lane reads a valid row (encode_walk.h)
     c.in_ptr = (ecp64)(uintptr_t)P.in_ptr;
     c.in_bitoff = (ecp32)(uintptr_t)P.in_bitoff;
-    c.sym_off = P.sym_off; c.sym_data = P.sym_data; c.out = nullptr; c.lout = nullptr;
+    c.sym_off = P.sym_off; c.sym_data = P.sym_data; c.out = nullptr; c.lout = nullptr; c.stage = nullptr;
   }
   template <int MODE>
   static __device__ __forceinline__ void walk(Ctx& c, ELane& L) { S::template walk<MODE>(c, L); }

@@ -22,7 +22,38 @@ namespace rh {
 
 constexpr int M_SIZE = 0, M_DIRECT = 1, M_STAGED = 2;   // what a walk does with the bytes it produces
 
+// Phase timing (RUHVRO_HIP_PROFILE=1 builds): lane 0 of every wave adds the shader-clock cycles between marks to
+// P.prof[slot]; the host prints per-wave means.  Compiled out otherwise.
+#ifdef RH_PROFILE
+struct PhaseClock {
+  unsigned long long pd[24], tprev;
+  __device__ __forceinline__ void init() {
+    for (int i = 0; i < 24; i++) pd[i] = 0;
+    tprev = clock64();
+  }
+  __device__ __forceinline__ void mark(int slot) {
+    const unsigned long long t = clock64();
+    pd[slot] += t - tprev;
+    tprev = t;
+  }
+  __device__ __forceinline__ void flush(unsigned long long* prof) const {
+    if ((threadIdx.x & 63) == 0 && prof) {
+      unsigned long long* row = prof + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63) * 32;
+      for (int i = 0; i < 24; i++)
+        if (pd[i]) atomicAdd(&row[i], pd[i]);
+    }
+  }
+};
+#else
+struct PhaseClock {
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void flush(unsigned long long*) const {}
+};
+#endif
+
 struct ELane {
+  PhaseClock clk;
   uint32_t len;        // bytes produced so far by this row (size pass: counted; emit pass: cursor)
   uint32_t err;
   int64_t edetail;
@@ -114,6 +145,32 @@ __device__ __forceinline__ void ld_32(const RH_GLOBAL uint8_t* s, uint32_t (&w)[
   w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w; w[8] = 0;
 }
 
+// The first 32 bytes of a string, fetched ahead of its put (e_string_fetch): a string costs the walk no HBM round trip
+// of its own when its bytes were requested together with those of the row's other strings.
+struct Str32 { uint32_t w[9]; };
+
+// put_bytes with bytes [0, 32) already in registers
+template <int MODE, class Ctx>
+__device__ __forceinline__ void put_bytes_pf(const Ctx& c, ELane& L, const RH_GLOBAL uint8_t* s, uint32_t n, const Str32& pf) {
+  if (MODE == M_DIRECT) {
+    RH_GLOBAL uint8_t* d = c.out + L.len;
+    uint32_t j = 0;
+    for (; j + 8 <= n; j += 8) *reinterpret_cast<RH_GLOBAL u64u*>(d + j) = *reinterpret_cast<const RH_GLOBAL u64u*>(s + j);
+    for (; j < n; j++) d[j] = s[j];
+  }
+  if (MODE == M_STAGED) {
+    RH_LDS uint8_t* d = c.lout + L.len;
+    if (n > 0) lds_put_32(d, pf.w, n < 32u ? n : 32u);
+    for (uint32_t j = 32; j < n; j += 32) {
+      uint32_t w[9];
+      ld_32(s + j, w);
+      const uint32_t m = n - j;
+      lds_put_32(d + j, w, m < 32u ? m : 32u);
+    }
+  }
+  L.len += n;
+}
+
 template <int MODE, class Ctx>
 __device__ __forceinline__ void put_bytes(const Ctx& c, ELane& L, const RH_GLOBAL uint8_t* s, uint32_t n) {
   if (MODE == M_DIRECT) {
@@ -165,6 +222,12 @@ __device__ __forceinline__ SpanV e_span_load(const Ctx& c, const Op op) {       
   SpanV v;
   v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
   const RH_GLOBAL uint32_t* off = reinterpret_cast<const RH_GLOBAL uint32_t*>(c.in(op.buf1));
+  if (op.dom != 0) {      // rows of a child domain are scattered over the lanes: one 8-byte request per lane, not two
+    const uint64_t o = *reinterpret_cast<const RH_GLOBAL u64u*>(off + r);     // dwords (for consecutive rows two dword loads win)
+    v.s0 = (uint32_t)o;
+    v.s1 = (uint32_t)(o >> 32);
+    return v;
+  }
   v.s0 = off[r];
   v.s1 = off[r + 1];
   return v;
@@ -193,9 +256,36 @@ __device__ __forceinline__ void e_fixed_put(const Ctx& c, ELane& L, const Op op,
   else put_byte<MODE>(c, L, (uint8_t)(v.bits & 1));
 }
 
-// write_string, fast_encode.rs:593-597
+// write_string, fast_encode.rs:593-597: e_string_fetch / e_string_cofetch request the bytes, e_string_put_pf / _cf write them
+// The second-level loads of a row, issued for several strings at once as soon as their spans are known: every lane
+// reads 32 bytes at a valid offset (offsets of null slots are valid too; the host pads every data buffer by 64 bytes).
+// The kernel is bound by the L1 (TCP) access rate, which a scattered per-lane load costs ~64-90 accesses per wave
+// instruction whatever its width: no second 16-byte load when no string of the wave needs it.
 template <int MODE, class Ctx>
-__device__ __forceinline__ void e_string_put(const Ctx& c, ELane& L, const Op op, const SpanV v) {
+__device__ __forceinline__ Str32 e_string_fetch(const Ctx& c, const Op op, const SpanV v) {
+  Str32 d;
+#pragma unroll
+  for (int k = 0; k < 9; k++) d.w[k] = 0;
+  if (MODE == M_SIZE) return d;
+  const RH_GLOBAL uint8_t* s = reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0;
+  const uint32_t n = v.s1 - v.s0;
+  if (__any(n > 16u)) {
+    ld_32(s, d.w);
+  } else if (__any(n > 8u)) {
+    const v4w a = *reinterpret_cast<const RH_GLOBAL v4wu*>(s);
+    d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w;
+  } else {
+    const uint64_t a = *reinterpret_cast<const RH_GLOBAL u64u*>(s);
+    d.w[0] = (uint32_t)a; d.w[1] = (uint32_t)(a >> 32);
+  }
+  return d;
+}
+// A use of both 16-byte halves AFTER the put: without it the compiler sinks the fetch into the branch that consumes
+// it (a nullable string's `valid` side), i.e. back behind the wait it was hoisted to avoid.
+__device__ __forceinline__ void keep_fetched(const Str32& pf) { asm volatile("" ::"v"(pf.w[0]), "v"(pf.w[4])); }
+
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_string_put_pf1(const Ctx& c, ELane& L, const Op op, const SpanV v, const Str32& pf) {
   if (!L.writes()) return;
   if (op.flags & F_NULLABLE) {
     put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
@@ -203,7 +293,113 @@ __device__ __forceinline__ void e_string_put(const Ctx& c, ELane& L, const Op op
   }
   const uint32_t n = v.s1 - v.s0;
   put_varint<MODE>(c, L, (int64_t)n);
-  put_bytes<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0, n);
+  put_bytes_pf<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0, n, pf);
+}
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_string_put_pf(const Ctx& c, ELane& L, const Op op, const SpanV v, const Str32& pf) {
+  e_string_put_pf1<MODE>(c, L, op, v, pf);
+  if (MODE != M_SIZE) keep_fetched(pf);
+}
+// Cooperative fetch (rows of domain 0, staged emit): the strings of a wave's 64 consecutive rows are one contiguous
+// byte range of the column.  When it is at most kStageBytes, lane l requests the ALIGNED 16 bytes [base + 16 l, +16)
+// -- one fully coalesced load for the wave (16 L1 accesses) instead of two scattered per-lane ones (~160) -- and the
+// put side transposes through the wave's LDS staging area: ds_write_b128, then every lane reads its own bytes back
+// as aligned dwords + v_alignbyte.  No barrier: a wave's DS instructions execute in order.
+struct StrF { Str32 pf; uint32_t base; bool coop; };
+
+template <int MODE, class Ctx>
+__device__ __forceinline__ StrF e_string_cofetch(const Ctx& c, const Op op, const SpanV v) {
+  StrF f;
+  f.base = 0; f.coop = false;
+  if (MODE == M_STAGED && c.stage) {
+    const uint32_t b = __builtin_amdgcn_readfirstlane(v.s0) & ~15u;
+    const uint32_t e = __builtin_amdgcn_readlane(v.s1, 63);
+    if (e - b <= kStageBytes) {                              // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 9; k++) f.pf.w[k] = 0;
+      f.coop = true; f.base = b;
+      const uint32_t o = b + 16u * (threadIdx.x & 63u);
+      if (o < e) {
+        const v4w a = *reinterpret_cast<const RH_GLOBAL v4w*>(reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + o);
+        f.pf.w[0] = a.x; f.pf.w[1] = a.y; f.pf.w[2] = a.z; f.pf.w[3] = a.w;
+      }
+      return f;
+    }
+  }
+  f.pf = e_string_fetch<MODE>(c, op, v);
+  return f;
+}
+
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_string_put_cf(const Ctx& c, ELane& L, const Op op, const SpanV v, const StrF& f) {
+  if (MODE != M_STAGED || !f.coop) {                          // wave-uniform
+    e_string_put_pf<MODE>(c, L, op, v, f.pf);
+    return;
+  }
+  RH_LDS uint8_t* st = c.stage;
+  v4w a; a.x = f.pf.w[0]; a.y = f.pf.w[1]; a.z = f.pf.w[2]; a.w = f.pf.w[3];
+  *reinterpret_cast<RH_LDS v4w*>(st + 16u * (threadIdx.x & 63u)) = a;        // every lane, present or not
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  const uint32_t n = v.s1 - v.s0;
+  put_varint<MODE>(c, L, (int64_t)n);
+  if (n > 0) {
+    const uint32_t p = v.s0 - f.base;                         // <= kStageBytes; reads end before kStageStride
+    const RH_LDS uint32_t* q = reinterpret_cast<const RH_LDS uint32_t*>(st + (p & ~3u));
+    const uint32_t sh = p & 3u;
+    uint32_t w[9];
+    uint32_t prev = q[0];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t next = q[k + 1];
+      w[k] = __builtin_amdgcn_alignbyte(next, prev, sh);
+      prev = next;
+    }
+    w[8] = 0;
+    RH_LDS uint8_t* d = c.lout + L.len;
+    lds_put_32(d, w, n < 32u ? n : 32u);
+    const RH_GLOBAL uint8_t* s = reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0;
+    for (uint32_t j = 32; j < n; j += 32) {
+      uint32_t x[9];
+      ld_32(s + j, x);
+      const uint32_t m = n - j;
+      lds_put_32(d + j, x, m < 32u ? m : 32u);
+    }
+  }
+  L.len += n;
+}
+
+// first 16 bytes of an enum's symbol text (symbols of <= 16 bytes are matched in registers)
+// ... of an enum whose longest symbol has NB bytes: no wider a load than that
+template <int NB, class Ctx>
+__device__ __forceinline__ v4w e_enum_fetch_n(const Ctx& c, const Op op, const SpanV v) {
+  const RH_GLOBAL uint8_t* s = reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf2)) + v.s0;
+  v4w a;
+  a.x = 0; a.y = 0; a.z = 0; a.w = 0;
+  if (NB <= 4) {
+    a.x = *reinterpret_cast<const RH_GLOBAL u32u*>(s);
+  } else if (NB <= 8) {
+    const uint64_t x = *reinterpret_cast<const RH_GLOBAL u64u*>(s);
+    a.x = (uint32_t)x; a.y = (uint32_t)(x >> 32);
+  } else {
+    a = *reinterpret_cast<const RH_GLOBAL v4wu*>(s);
+  }
+  return a;
+}
+template <int MODE, class Ctx, class Find>
+__device__ __forceinline__ void e_enum_put_pf(const Ctx& c, ELane& L, const Op op, const SpanV v, int pc, const v4w a, const Find& find) {
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  const int32_t found = find(a, v.s1 - v.s0);
+  if (found < 0) { L.err = EE_ENUM; L.eop = (uint32_t)pc; L.edetail = c.row(op.dom); }
+  else put_varint<MODE>(c, L, found);
 }
 
 // symbol text -> index by comparing against the schema's symbol table in HBM (any symbol length)
@@ -390,6 +586,7 @@ __device__ __forceinline__ void e_emit_body(const EParams& P, uint8_t* smem) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Geo g = egeometry(P, blockIdx.x);
   ELane L;
+  L.clk.init();
   elane_init(L, g, tid);
   typename W::Ctx c;
   W::init(c, P, cursors, g, tid);
@@ -397,6 +594,7 @@ __device__ __forceinline__ void e_emit_body(const EParams& P, uint8_t* smem) {
   const uint32_t incl = wave_incl_scan(mylen, lane);
   if (lane == 63) misc[4 + wave] = incl;
   __syncthreads();
+  L.clk.mark(0);
   const uint32_t base = P.blockbase[blockIdx.x];                        // chunk-relative first byte of this workgroup
   uint32_t before = 0, total = 0;
 #pragma unroll
@@ -414,12 +612,16 @@ __device__ __forceinline__ void e_emit_body(const EParams& P, uint8_t* smem) {
   const uint32_t shift = base & 15u;          // data is 256-byte aligned: LDS window offset == HBM address (mod 16)
   c.out = data + base + rel;
   c.lout = (RH_LDS uint8_t*)(window + shift + rel);
+  c.stage = P.stage_bytes ? (RH_LDS uint8_t*)(window + P.win_bytes + wave * kStageStride) : (RH_LDS uint8_t*)nullptr;
   if (shift + total > P.win_bytes) {          // uniform: this workgroup's rows do not fit the window
     W::template walk<M_DIRECT>(c, L);
     return;
   }
+  L.clk.mark(1);
   W::template walk<M_STAGED>(c, L);
+  L.clk.mark(20);
   __syncthreads();
+  L.clk.mark(21);
   // window[shift, shift+total) -> data[base, base+total): byte head up to the first 16-byte boundary, aligned
   // 16-byte body (ds_read_b128 -> global_store_dwordx4, consecutive lanes = consecutive lines), byte tail
   RH_GLOBAL uint8_t* dst = data + base;
@@ -432,6 +634,8 @@ __device__ __forceinline__ void e_emit_body(const EParams& P, uint8_t* smem) {
   for (uint32_t i = tid; i < nvec; i += kBlock) dst16[i] = src16[i];
   const uint32_t done = head + (nvec << 4);
   if (tid < total - done) dst[done + tid] = window[shift + done + tid];
+  L.clk.mark(22);
+  L.clk.flush(P.prof);
 }
 
 // LDS bytes in front of rh_e_emit's staging window: cursor words of the walker + misc[8]

@@ -1867,13 +1867,42 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   uint64_t win = nblocks ? sum / nblocks : 0;
   win = align_up(win + win * 15 / 100 + 2048, 16);
   win = std::min<uint64_t>(win, (65536 - lds) & ~15ull);
+  // string staging areas of the specialised kernel (encode_walk.h e_string_cofetch), behind the window; the window gives
+  // up slack rather than the 4-workgroups-per-CU occupancy when the mean workgroup still fits with ~3 % + 512 bytes
+  uint32_t stage = 0;
+  if (sk) {
+    stage = 4 * rh::kStageStride;
+    const uint64_t mean = nblocks ? sum / nblocks : 0;
+    const uint64_t cap4 = (40960 - lds - stage) & ~15ull;
+    if (win + stage + lds > 40960 && mean + mean * 3 / 100 + 512 <= cap4) win = cap4;
+    win = std::min<uint64_t>(win, (65536 - lds - stage) & ~15ull);
+  }
   E.win_bytes = (uint32_t)win;
+  E.stage_bytes = stage;
+  static const bool profile = [] { const char* e = std::getenv("RUHVRO_HIP_PROFILE"); return e && *e && *e != '0'; }();
+  Lease prof_buf;
+  if (profile && sk) {
+    prof_buf = Lease(dev_pool(), 64 * 32 * 8, device);
+    HIPCHK(hipMemsetAsync(prof_buf.ptr(), 0, 64 * 32 * 8, stream));
+    E.prof = (unsigned long long*)prof_buf.ptr();
+  }
   ev.rec(3, stream);
-  if (n > 0 && launch(true, lds + E.win_bytes)) throw HipError("e_emit launch failed");
+  if (n > 0 && launch(true, lds + E.win_bytes + E.stage_bytes)) throw HipError("e_emit launch failed");
   ev.rec(4, stream);
   HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), 16, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
   check_bad(hctrl.ptr(), "emit");
+  if (profile && sk) {     // phase cycles of rh_espec_emit (encode_walk.h PhaseClock): 0 prologue, 1 offsets, 2..19 walk stretches, 20..22 tail
+    unsigned long long hr[64 * 32], h[32] = {0};
+    HIPCHK(hipMemcpy(hr, prof_buf.ptr(), sizeof hr, hipMemcpyDeviceToHost));
+    for (int r0 = 0; r0 < 64; r0++)
+      for (int i = 0; i < 32; i++) h[i] += hr[r0 * 32 + i];
+    const double waves = (double)nblocks * 4;
+    std::fprintf(stderr, "[ruhvro_hip profile] e_emit cycles/wave: rowlen+scan+barrier=%.0f offsets=%.0f | walk:", h[0] / waves, h[1] / waves);
+    for (int i = 2; i < 20; i++)
+      if (h[i]) std::fprintf(stderr, " [%d]=%.0f", i, h[i] / waves);
+    std::fprintf(stderr, " | walk_tail=%.0f barrier=%.0f stream_out=%.0f\n", h[20] / waves, h[21] / waves, h[22] / waves);
+  }
 
   // ---- results -> host, one slab shared by the k BinaryArrays
   Timer td;

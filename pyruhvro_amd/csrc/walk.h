@@ -157,6 +157,23 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
 
 template <bool WIDE, class Src>
 __device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
+  // A store instruction costs the CU's store path about (width x 64 lanes) / 18 cycles WHATEVER the number of active
+  // lanes (tools/storecost.hip), so a column whose lengths straddle 16 pays for the 16-byte class and the 8-byte class
+  // separately.  When the wave has a string of 8..15 bytes, every string of 8 bytes and more is written with 8-byte
+  // stores instead (the last one ending at the string's end, overlapping): ceil(maxlen / 8) fuller instructions
+  // (k_emit -1.5 %, profiles/r02i_variants_ab.txt).  Not when the wave also holds a long string: 16 bytes a store there.
+  if (__any(len >= 8 && len < 16) && !__any(len > 64)) {
+    if (len >= 8) {
+      uint32_t j = 0;
+      for (;;) {
+        const uint32_t off = j + 8 <= len ? j : len - 8;
+        st_at<u64u, WIDE>(base, d + off, s.ld8(sp + off));
+        j += 8;
+        if (j >= len) break;
+      }
+      return;
+    }
+  }
   if (len >= 16) {
     uint32_t j = 0;
     for (; j + 32 <= len; j += 32) {
