@@ -225,6 +225,39 @@ def test_rows_beyond_the_staging_window_take_the_direct_store_path():
         _check(batch, s, k)
 
 
+def test_string_fetch_classes_and_the_cooperative_range_limit():
+    """The specialised emit kernel fetches string bytes three ways: cooperatively through the wave's LDS staging area
+    (top-level column, the 64 rows' bytes within 1 KB), per lane with 8 / 16 / 32 bytes by the wave's longest string,
+    and 32 bytes at a time past the first 32.  Stretches of 256 rows drive every class and both sides of the range
+    limit, with nulls, empty strings and list items of every class in between."""
+    s = cases.ENC_WINDOW_SCHEMA
+    lens = [0, 1, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 40, 63, 64, 65, 100]
+    t, o, xs = [], [], []
+
+    def stretch(tl, ol, xl):
+        for i in range(256):
+            j = len(t)
+            t.append(chr(97 + j % 26) * tl(i))
+            n = ol(i)
+            o.append(None if n is None else chr(65 + j % 26) * n)
+            xs.append([chr(48 + (j + q) % 10) * xl(i, q) for q in range(i % 4)])
+
+    stretch(lambda i: lens[i % len(lens)], lambda i: None if i % 3 == 0 else lens[(i * 7) % len(lens)], lambda i, q: lens[(i + q) % len(lens)])
+    stretch(lambda i: i % 9, lambda i: i % 8, lambda i, q: (i + q) % 9)                  # nothing over 8 bytes
+    stretch(lambda i: 9 + i % 8, lambda i: None if i % 2 else 16, lambda i, q: 10 + q)   # 9..16 bytes
+    stretch(lambda i: 16, lambda i: 15, lambda i, q: 17 + q)                             # 64 x 16 = the range limit exactly
+    stretch(lambda i: 16 + (i % 64 == 63), lambda i: 16 if i % 64 else 17, lambda i, q: 33)   # one byte past it
+    stretch(lambda i: 200 if i % 64 == 5 else 3, lambda i: None if i % 64 else 1500, lambda i, q: 2 if q else 90)
+    n = len(t)
+    rb = pa.RecordBatch.from_arrays([pa.array(range(n), pa.int64()), pa.array(t), pa.array(o), pa.array(xs, pa.list_(pa.string()))],
+                                    names=["id", "t", "o", "xs"])
+    exp = py_encoder.serialize_record_batch(rb, s, 1)
+    batch = c_walker.decode(_datums(exp), s)
+    for k in (1, 5):
+        _check(batch, s, k)
+    _check(batch.slice(37, n - 100), s, 3)
+
+
 def test_enum_symbols_short_and_longer_than_sixteen_bytes():
     """The specialised kernel folds symbols of <= 16 bytes into constant compares and sends longer ones through the
     symbol table; both must find every symbol and reject near misses with the reference's message."""
