@@ -1053,13 +1053,111 @@ void run_threads(unsigned nt, const std::function<void(unsigned)>& f) {
   for (auto& x : th) x.join();
 }
 
+// A pool of host threads that lives for one call: parallel_for hands out task indices to the workers and returns when
+// all are done.  The gather of a pipelined call runs shard after shard on it (creating 2 x 32 threads per shard instead
+// costs more than the gather itself).
+class CallPool {
+ public:
+  explicit CallPool(unsigned workers) {
+    for (unsigned i = 0; i < workers; i++) th_.emplace_back([this] { work(); });
+  }
+  ~CallPool() {
+    { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+    cv_start_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  unsigned workers() const { return (unsigned)th_.size(); }
+  void parallel_for(unsigned ntasks, const std::function<void(unsigned)>& f) {     // one caller at a time
+    if (ntasks == 0) return;
+    std::unique_lock<std::mutex> l(mu_);
+    fn_ = &f; ntasks_ = ntasks; next_ = 0; left_ = ntasks; gen_++;
+    cv_start_.notify_all();
+    cv_done_.wait(l, [&] { return left_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_start_.wait(l, [&] { return stop_ || (gen_ != seen && next_ < ntasks_); });
+      if (stop_) return;
+      seen = gen_;
+      while (fn_ && next_ < ntasks_) {
+        const unsigned t = next_++;
+        const std::function<void(unsigned)>* f = fn_;
+        l.unlock();
+        (*f)(t);
+        l.lock();
+        if (--left_ == 0) cv_done_.notify_all();
+        if (gen_ != seen) break;          // (cannot happen before left_ == 0; kept for clarity)
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_start_, cv_done_;
+  const std::function<void(unsigned)>* fn_ = nullptr;
+  unsigned ntasks_ = 0, next_ = 0, left_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+// Record slices [r0, r0 + n) gathered into pooled PINNED memory together with their offsets, laid out exactly like the
+// device staging buffer: [16 bytes lead][payload][pad to kAlign][u64 offsets n+1].
+struct Gathered {
+  Lease pin;
+  uint64_t tot = 0, o_off = 0, total_bytes = 0;
+  float pack_ms = 0.f;
+  static constexpr uint64_t lead = 16;
+};
+
+// `par(ntasks, f)` runs f(0..ntasks-1) on host threads and returns when all are done
+Gathered gather_slices(const Source& src, uint64_t r0, uint64_t n, int device, unsigned nt_in,
+                       const std::function<void(unsigned, const std::function<void(unsigned)>&)>& par) {
+  Range rg("ruhvro_hip:gather");
+  Timer tp;
+  Gathered g;
+  const uint8_t* const* ptrs = src.ptrs + r0;
+  const uint64_t* lens = src.lens + r0;
+  // pass 1: byte totals per thread range; pass 2: offsets + bytes
+  const unsigned nt = n >= 4096 ? std::max(1u, nt_in) : 1u;
+  auto lo_of = [&](unsigned t) { return n * t / nt; };
+  std::vector<uint64_t> part(nt + 1, 0);
+  par(nt, [&](unsigned t) {
+    uint64_t sum = 0;
+    for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) sum += lens[i];
+    part[t + 1] = sum;
+  });
+  for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
+  g.tot = part[nt];
+  g.o_off = align_up(Gathered::lead + g.tot + 32, kAlign);
+  g.total_bytes = g.o_off + 8 * (n + 1);
+  g.pin = Lease(pin_pool(), g.total_bytes, device);
+  uint8_t* hdst = g.pin.ptr() + Gathered::lead;
+  uint64_t* hoff = (uint64_t*)(g.pin.ptr() + g.o_off);
+  par(nt, [&](unsigned t) {
+    uint64_t pos = part[t];
+    for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) {
+      hoff[i] = pos;
+      std::memcpy(hdst + pos, ptrs[i], lens[i]);
+      pos += lens[i];
+    }
+  });
+  hoff[n] = g.tot;
+  g.pack_ms = tp.ms();
+  return g;
+}
+
 // Rows [r0, r1) of the source: (gather +) H2D, the kernels, D2H -- all on `stream`.
 // Slices are gathered into pooled PINNED memory together with their offsets, laid out exactly like the device
 // staging buffer, so the range goes up in ONE copy (the reference's BinaryArray::from_vec, deserialize.rs:90, but
 // per shard -- a later shard gathers while an earlier one is on the wire -- and straight into DMA-able memory).
 void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uint64_t num_chunks, const ChunkGeo* geo_in,
                   const rh_opts* opts, int device, hipStream_t stream, ArrowArray* out_chunks, uint32_t* out_k,
-                  rh_stats* stats, Turnstile* h2d_gate, Turnstile* d2h_gate, uint32_t ticket, unsigned pack_threads) {
+                  rh_stats* stats, Turnstile* h2d_gate, Turnstile* d2h_gate, uint32_t ticket, unsigned pack_threads,
+                  Gathered* pre = nullptr) {
   const uint64_t n = r1 - r0;
   rh_opts o = default_opts();
   o.device = device;
@@ -1073,37 +1171,16 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   ChunkGeo geo;
   if (geo_in) geo = *geo_in;
   if (src.slices()) {
-    Range rg("ruhvro_hip:gather");
-    Timer tp;
-    const uint8_t* const* ptrs = src.ptrs + r0;
-    const uint64_t* lens = src.lens + r0;
-    // pass 1: byte totals per thread range; pass 2: offsets + bytes
-    const unsigned nt = n >= 4096 ? std::max(1u, pack_threads) : 1u;
-    auto lo_of = [&](unsigned t) { return n * t / nt; };
-    std::vector<uint64_t> part(nt + 1, 0);
-    run_threads(nt, [&](unsigned t) {
-      uint64_t sum = 0;
-      for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) sum += lens[i];
-      part[t + 1] = sum;
-    });
-    for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
-    const uint64_t tot = part[nt];
-    const uint64_t lead = 16;
-    const uint64_t o_off = align_up(lead + tot + 32, kAlign);
-    const uint64_t total_bytes = o_off + 8 * (n + 1);
-    pin = Lease(pin_pool(), total_bytes, device);
-    uint8_t* hdst = pin.ptr() + lead;
-    uint64_t* hoff = (uint64_t*)(pin.ptr() + o_off);
-    run_threads(nt, [&](unsigned t) {
-      uint64_t pos = part[t];
-      for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) {
-        hoff[i] = pos;
-        std::memcpy(hdst + pos, ptrs[i], lens[i]);
-        pos += lens[i];
-      }
-    });
-    hoff[n] = tot;
-    pack_ms = tp.ms();
+    // a pipelined call gathered this shard already (in shard order, on the call's thread pool); else gather here
+    Gathered own;
+    if (!pre) {
+      own = gather_slices(src, r0, n, device, pack_threads,
+                          [](unsigned nt, const std::function<void(unsigned)>& f) { run_threads(nt, f); });
+      pre = &own;
+    }
+    pin = std::move(pre->pin);
+    pack_ms = pre->pack_ms;
+    const uint64_t tot = pre->tot, lead = Gathered::lead, o_off = pre->o_off, total_bytes = pre->total_bytes;
     din = Lease(dev_pool(), total_bytes, device);
     {
       TurnstilePass pass(h2d_gate, ticket);
@@ -1255,8 +1332,43 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
 
   const uint64_t sz = n / k, rows_last = n - (uint64_t)(k - 1) * sz;
   const size_t ns = shards.size();
-  // every shard gathers its own slices (in parallel with the others): share the host cores between them
-  const unsigned pack_threads = std::max(1u, std::min(hw, 32u) / (unsigned)std::max<size_t>(ns, 1));
+  // Record slices are gathered shard after shard by ONE pool of host threads, so the first shard is on the wire after
+  // 1/ns of the gather time (side by side every shard would finish its gather at about the same, late, moment); each
+  // shard's own thread waits for its block and takes it through H2D -> kernels -> D2H.
+  const unsigned pack_threads = std::max(1u, std::min(hw, 32u));
+  struct Ready {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> state;                 // 0 pending, 1 gathered, 2 failed
+    std::vector<Gathered> block;
+    std::vector<std::exception_ptr> err;
+  } ready;
+  ready.state.assign(ns, 0);
+  ready.block.resize(ns);
+  ready.err.resize(ns);
+  std::thread gatherer;
+  if (src.slices()) {
+    gatherer = std::thread([&] {
+      CallPool pool(pack_threads);
+      auto par = [&](unsigned nt, const std::function<void(unsigned)>& f) { pool.parallel_for(nt, f); };
+      for (size_t g = 0; g < ns; g++) {
+        const Shard& sh = shards[g];
+        char st = 1;
+        try {
+          if (sh.c1 > sh.c0) {
+            HIPCHK(hipSetDevice(sh.device));
+            const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
+            ready.block[g] = gather_slices(src, r0, r1 - r0, sh.device, pack_threads, par);
+          }
+        } catch (...) {
+          ready.err[g] = std::current_exception();
+          st = 2;
+        }
+        { std::lock_guard<std::mutex> l(ready.mu); ready.state[g] = st; }
+        ready.cv.notify_all();
+      }
+    });
+  }
   std::vector<rh_stats> gstats(ns);
   for (auto& gs : gstats) std::memset(&gs, 0, sizeof gs);
   std::vector<std::exception_ptr> failed(ns);
@@ -1279,9 +1391,16 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
           geo.sz = sz;
           geo.rows_last = sh.c1 == k ? rows_last : sz;
           geo.payload_bytes = 0;           // decode_range fills it in
+          Gathered* pre = nullptr;
+          if (src.slices()) {
+            std::unique_lock<std::mutex> l(ready.mu);
+            ready.cv.wait(l, [&] { return ready.state[g] != 0; });
+            if (ready.state[g] == 2) std::rethrow_exception(ready.err[g]);
+            pre = &ready.block[g];
+          }
           Timer tsh;
           decode_range(s, src, r0, r1, 0, &geo, &sopts, sh.device, st, out_chunks + sh.c0, nullptr,
-                       want ? &gstats[g] : nullptr, &h2d_gates[sh.gate], &d2h_gates[sh.gate], sh.ticket, pack_threads);
+                       want ? &gstats[g] : nullptr, &h2d_gates[sh.gate], &d2h_gates[sh.gate], sh.ticket, pack_threads, pre);
           gstats[g].total_ms = tsh.ms();
         }
       } catch (...) {
@@ -1293,6 +1412,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
     });
   }
   for (auto& t : th) t.join();
+  if (gatherer.joinable()) gatherer.join();
   for (size_t g = 0; g < ns; g++) {
     if (!failed[g]) continue;
     for (uint32_t c = 0; c < k; c++)        // the call fails as a whole: drop what the other shards produced
@@ -1313,7 +1433,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
       stats->blocks += gs.blocks;
       rh_stats& d = per_dev[shards[g].gate];
       d.h2d_ms += gs.h2d_ms; d.size_kernel_ms += gs.size_kernel_ms; d.scan_kernel_ms += gs.scan_kernel_ms;
-      stats->pack_ms = std::max(stats->pack_ms, gs.pack_ms);      // the shards gather side by side
+      stats->pack_ms += gs.pack_ms;                                // the shards are gathered one after the other
       d.emit_kernel_ms += gs.emit_kernel_ms; d.d2h_ms += gs.d2h_ms;
       if (gs.records) { stats->specialized = gs.specialized; stats->lds_bytes = gs.lds_bytes; }
     }
