@@ -384,6 +384,25 @@ struct HostProf {
   ~HostProf() { if (on) std::fprintf(stderr, "[ruhvro_hip hostprof us]%s\n", line.c_str()); }
 };
 
+// RUHVRO_HIP_TIMELINE=1: one stderr line per stage boundary of every shard of a host call, in ms since the call began
+// (when the gather of a shard ended, when it held each PCIe direction): shows where a pipelined call waits.
+struct Timeline {
+  static bool on() {
+    static const bool e = [] { const char* v = std::getenv("RUHVRO_HIP_TIMELINE"); return v && *v && *v != '0'; }();
+    return e;
+  }
+  static std::chrono::steady_clock::time_point& t0() {
+    static std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    return t;
+  }
+  static void start() { if (on()) t0() = std::chrono::steady_clock::now(); }
+  static void mark(uint32_t shard, const char* what) {
+    if (!on()) return;
+    std::fprintf(stderr, "[ruhvro_hip timeline] %8.3f ms  shard %u  %s\n",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0()).count(), shard, what);
+  }
+};
+
 rh_opts default_opts() {
   rh_opts o;
   std::memset(&o, 0, sizeof o);
@@ -1184,11 +1203,13 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
     din = Lease(dev_pool(), total_bytes, device);
     {
       TurnstilePass pass(h2d_gate, ticket);
+      Timeline::mark(ticket, "h2d begin");
       Range rh("ruhvro_hip:h2d");
       Timer th;
       HIPCHK(hipMemcpyAsync(din.ptr(), pin.ptr(), total_bytes, hipMemcpyHostToDevice, stream));
       if (h2d_gate || stats) HIPCHK(hipStreamSynchronize(stream));   // a gate orders the shards of one link; else the stream does
       h2d = th.ms();
+      Timeline::mark(ticket, "h2d end");
     }
     base = din.ptr() + lead;
     d_offsets = (const uint64_t*)(din.ptr() + o_off);
@@ -1219,13 +1240,16 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   std::unique_ptr<rh_device_result> r(decode_device_impl(s, base, d_offsets, data_end, n, num_chunks, &o, stats,
                                                          geo_in ? &geo : nullptr));
   pin.release();            // the staging copy is done (decode_device_impl synchronised the stream)
+  Timeline::mark(ticket, "kernels end");
   float d2h = 0.f;
   {
     TurnstilePass pass(d2h_gate, ticket);
+    Timeline::mark(ticket, "d2h begin");
     Range rd("ruhvro_hip:d2h+export");
     Timer td;
     to_host_impl(r.get(), out_chunks, stream);
     d2h = td.ms();
+    Timeline::mark(ticket, "d2h end");
   }
   if (out_k) *out_k = r->k;
   if (stats) {
@@ -1258,6 +1282,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
                      ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats) {
   require_device();
   Timer total;
+  Timeline::start();
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const uint32_t k = rh_clamp_chunks(n, num_chunks);
   std::memset(out_chunks, 0, sizeof(ArrowArray) * k);      // the failure paths release whatever was produced
@@ -1359,6 +1384,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
             HIPCHK(hipSetDevice(sh.device));
             const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
             ready.block[g] = gather_slices(src, r0, r1 - r0, sh.device, pack_threads, par);
+            Timeline::mark((uint32_t)g, "gathered");
           }
         } catch (...) {
           ready.err[g] = std::current_exception();
