@@ -169,6 +169,31 @@ def test_no_device_fails_loudly_no_cpu_fallback():
     assert "no HIP device" in str(ei.value)
 
 
+def test_list_extraction_holds_and_returns_every_reference():
+    """The CPython boundary takes one reference per record while the GIL is released and recovers the object from its
+    payload pointer afterwards: after a call that fails (no device here, or a bad element half way) every refcount is
+    back where it was, and a non-bytes element is named by index like PyO3's extraction error."""
+    import sys
+    recs = [bytes([i % 251]) * (1 + i % 40) for i in range(5000)]
+    probe = [recs[0], recs[2500], recs[-1]]
+    before = [sys.getrefcount(o) for o in probe]
+    with pytest.raises(RuntimeError):
+        P.deserialize_array_threaded(recs, SCHEMAS["cfg3"], 4)
+    assert [sys.getrefcount(o) for o in probe] == before
+    bad = list(recs)
+    bad[3000] = 5
+    before = [sys.getrefcount(o) for o in probe]     # (the second list holds a reference too)
+    with pytest.raises(TypeError) as ei:
+        P.deserialize_array_threaded(bad, SCHEMAS["cfg3"], 4)
+    assert "list element 3000: expected bytes, got int" in str(ei.value)
+    assert [sys.getrefcount(o) for o in probe] == before
+    mixed = [bytearray(b"ab"), b"cd"] * 10           # bytearray elements are copied into bytes the call owns
+    with pytest.raises(RuntimeError):
+        P.deserialize_array_threaded(mixed, SCHEMAS["cfg3"], 2)
+    with pytest.raises(TypeError):
+        P.deserialize_array_threaded((b"x",), SCHEMAS["cfg3"], 1)
+
+
 def test_product_does_not_reference_the_oracle():
     """Nothing under pyruhvro_amd/ (nor the drop-in alias pyruhvro/) may import, link or execute the oracle -- directly
     or through a module that does: every import of every product module is followed, and the oracle, the test
