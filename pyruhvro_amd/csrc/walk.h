@@ -154,9 +154,15 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
   if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off) = v;
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
 }
+// byte offsets into a buffer: 64-bit when WIDE, else 32-bit END TO END -- an offset that is summed in 64 bits and
+// truncated at the store makes the compiler carry a zero-extended VGPR pair and add the base with a VALU instruction
+// (v_lshl_add_u64 + the `off` addressing form) instead of using the scalar-base form (72 VALU instructions of the emit
+// walk, k_emit -1.5 %: profiles/r02i_variants_ab.txt)
+template <bool WIDE> struct BufOff { typedef uint64_t type; };
+template <> struct BufOff<false> { typedef uint32_t type; };
 
 template <bool WIDE, class Src>
-__device__ __forceinline__ void copy_bytes(void* base, uint64_t d, const Src& s, uint32_t sp, uint32_t len) {
+__device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len) {
   // A store instruction costs the CU's store path about (width x 64 lanes) / 18 cycles WHATEVER the number of active
   // lanes (tools/storecost.hip), so a column whose lengths straddle 16 pays for the 16-byte class and the 8-byte class
   // separately.  When the wave has a string of 8..15 bytes, every string of 8 bytes and more is written with 8-byte
@@ -524,7 +530,7 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
         // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
         // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
         if (op.code == OP_STRING) {
-          copy_bytes<Ctx::kWide>(c.buf(op.buf2), (uint64_t)gb + o, src, spos, len);
+          copy_bytes<Ctx::kWide>(c.buf(op.buf2), (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
         } else {
           RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
           copy_plain(d, c.sym_data + spos, len);

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--kernel", default="emit", choices=sorted(KERNELS))
     ap.add_argument("--fast-only", action="store_true")
     ap.add_argument("--lines", type=int, default=0, help="also print the N hottest source lines")
+    ap.add_argument("--opcode", default="", help="also print the source lines that emit this opcode (e.g. v_lshl_add_u64)")
     ap.add_argument("--variant", default="", help="RUHVRO_HIP_VARIANT names (staged experimental code paths), comma separated")
     args = ap.parse_args()
     if args.variant:
@@ -90,6 +91,7 @@ def main():
     inside, cur = False, ("?", 0)
     agg = collections.defaultdict(lambda: [0, 0, 0, 0, 0])
     by_line = collections.Counter()
+    op_lines = collections.Counter()
     ops = collections.Counter()
     for l in lines:
         if l.startswith(kern + ":"):
@@ -116,6 +118,8 @@ def main():
         a[1 if t.startswith("v_") else 2 if t.startswith("s_") else 3 if t.startswith("ds_") else 4] += 1
         by_line[cur] += 1
         ops[t.split()[0]] += 1
+        if args.opcode and t.split()[0] == args.opcode:
+            op_lines[cur] += 1
     print(f"# {kern}, schema {args.schema}{', fast walk only' if args.fast_only else ''}"
           f"{', variant ' + args.variant if args.variant else ''}: static instructions per source function")
     print("%-58s %6s %6s %6s %5s %5s" % ("where", "total", "VALU", "SALU", "DS", "VMEM"))
@@ -125,6 +129,10 @@ def main():
     print("opcodes:", ", ".join(f"{o} {n}" for o, n in ops.most_common(24)))
     for k, v in by_line.most_common(args.lines):
         print(f"  {k[0]}:{k[1]}  {v}")
+    if args.opcode:
+        print(f"{args.opcode} by source line:")
+        for k, v in op_lines.most_common(30):
+            print(f"  {k[0]}:{k[1]}  {v}")
 
 
 if __name__ == "__main__":
