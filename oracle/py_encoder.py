@@ -117,7 +117,83 @@ def _leaf_writer(s: S.AvroSchema, arr: pa.Array) -> Writer:
         return w
     if k == "null":
         return lambda out, row: None
+    w = _n4_writer(s, arr)
+    if w is not None:
+        return w
     raise EncodeError(f"fast_encode: unsupported schema: {k}")
+
+
+def _fixed_width_values(arr: pa.Array, width: int) -> List[bytes]:
+    """rows of a FixedSizeBinary / Decimal128 values buffer as written (value(row) ignores validity)."""
+    n = len(arr)
+    buf = arr.buffers()[1]
+    if buf is None:
+        return [b"\0" * width] * n
+    raw = buf.to_pybytes()
+    return [raw[(arr.offset + i) * width: (arr.offset + i + 1) * width] for i in range(n)]
+
+
+def _n4_writer(s: S.AvroSchema, arr: pa.Array):
+    """SURVEY 8(f) N4, the encode side (beyond the reference: fast_encode::is_supported is false for these types, and
+    so is the decode side's).  The wire forms are the Avro 1.11 specification's -- the mirror of py_walker._decode_n4:
+      bytes            varint length + the bytes
+      fixed(N)         the N bytes
+      decimal / bytes  varint length + the unscaled value as MINIMAL big-endian two's complement (what writers emit:
+                       BigInt::to_signed_bytes_be), 1..16 bytes
+      decimal / fixed  the unscaled value as N big-endian bytes (its low N bytes: sign-extended when N > its width)
+      uuid / string    varint 36 + lower-case 8-4-4-4-12 hex text of the 16 bytes
+      uuid / fixed(16) the 16 bytes
+      time-millis / time-micros   zig-zag int / long"""
+    k = s.kind
+    if k in ("time-millis", "time-micros"):
+        typ, dt = (pa.time32("ms"), np.int32) if k == "time-millis" else (pa.time64("us"), np.int64)
+        if arr.type != typ:
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        vals = _raw_values(arr, dt)
+        return lambda out, row: out.extend(zigzag(int(vals[row])))
+    if k == "bytes":
+        if not pa.types.is_binary(arr.type):
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        n = len(arr)
+        offs = np.frombuffer(arr.buffers()[1], dtype=np.int32, count=arr.offset + n + 1)[arr.offset:]
+        data = arr.buffers()[2].to_pybytes() if arr.buffers()[2] is not None else b""
+        vals = [data[int(offs[i]): int(offs[i + 1])] for i in range(n)]
+        return lambda out, row: (out.extend(zigzag(len(vals[row]))), out.extend(vals[row]))[0]
+    if k == "fixed" or (k == "uuid" and s.items is not None and s.items.kind == "fixed"):
+        width = s.size if k == "fixed" else 16
+        if not pa.types.is_fixed_size_binary(arr.type) or arr.type.byte_width != width:
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        vals = _fixed_width_values(arr, width)
+        return lambda out, row: out.extend(vals[row])
+    if k == "uuid":
+        if not pa.types.is_fixed_size_binary(arr.type) or arr.type.byte_width != 16:
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        vals = _fixed_width_values(arr, 16)
+
+        def wu(out, row):
+            h = vals[row].hex()
+            txt = f"{h[0:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:32]}".encode()
+            out.extend(zigzag(36))
+            out.extend(txt)
+        return wu
+    if k == "decimal":
+        if not pa.types.is_decimal128(arr.type) or arr.type.precision != s.precision or arr.type.scale != s.scale:
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        vals = [int.from_bytes(b, "little", signed=True) for b in _fixed_width_values(arr, 16)]
+        if s.items is not None and s.items.kind == "fixed":
+            size = s.items.size
+
+            def wf(out, row):
+                out.extend((vals[row] & ((1 << (8 * size)) - 1)).to_bytes(size, "big"))
+            return wf
+
+        def wb(out, row):
+            v = vals[row]
+            nb = max(1, ((v if v >= 0 else ~v).bit_length() + 8) // 8)     # minimal two's complement length
+            out.extend(zigzag(nb))
+            out.extend(v.to_bytes(nb, "big", signed=True))
+        return wb
+    return None
 
 
 def _split_null_union(s: S.AvroSchema):
@@ -235,10 +311,10 @@ def serialize_chunk(schema: S.AvroSchema, sa: pa.Array) -> pa.Array:
     return pa.array(rows, type=pa.binary())
 
 
-def serialize_record_batch(rb: pa.RecordBatch, schema_json: str, num_chunks: int) -> List[pa.Array]:
+def serialize_record_batch(rb: pa.RecordBatch, schema_json: str, num_chunks: int, extended: bool = False) -> List[pa.Array]:
     """serialize.rs:38-67: k = clamp(num_chunks, 1, max(rows, 1)); chunk i = rows [i*sz, (i+1)*sz), last takes the rest."""
     s = S.parse_schema(schema_json)
-    if not S.is_supported(s):
+    if not (S.is_supported_extended(s) if extended else S.is_supported(s)):
         raise EncodeError("schema is outside the fast encode path (fast_encode::is_supported == false)")
     sa = rb.to_struct_array()
     n = len(sa)

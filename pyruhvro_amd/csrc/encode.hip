@@ -102,6 +102,21 @@ struct EInterp {
           break;
         }
 
+        case OP_BIN: {                        // fixed / decimal / uuid (encode_walk.h e_bin_put)
+          if (wr) {
+            BinV v;
+            v.lo = 0; v.hi = 0;
+            const uint32_t r = c.row(op.dom);
+            v.valid = (op.flags & F_NULLABLE) ? c.bit(op.buf0, r) : true;
+            if (op.a != BN_FIXED && v.valid) {
+              const RH_GLOBAL u64u* p = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1)) + 2ull * r;
+              v.lo = p[0]; v.hi = p[1];
+            }
+            e_bin_put<MODE>(c, L, op, v);
+          }
+          break;
+        }
+
         case OP_REC_BEGIN: {                  // NullableRecord, 465-476: the struct's own validity
           L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
           bool present = false;

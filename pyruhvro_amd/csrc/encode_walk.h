@@ -241,6 +241,66 @@ __device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op) {
   return reinterpret_cast<const RH_GLOBAL int8_t*>(c.in(op.buf1))[c.row(op.dom)];
 }
 
+// SURVEY 8(f) N4 (beyond the reference, whose encoder gate is false for these types): fixed(N),
+// decimal and uuid leaves.  The 16 value bytes of a decimal / uuid row travel in registers; fixed(N) is copied from HBM.
+struct BinV { uint64_t lo, hi; bool valid; };
+
+template <class Ctx>
+__device__ __forceinline__ BinV e_bin_load(const Ctx& c, const Op op) {
+  const uint32_t r = c.row(op.dom);
+  BinV v;
+  v.lo = 0; v.hi = 0;
+  v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
+  if (op.a != BN_FIXED) {                                       // Decimal128 / FixedSizeBinary(16): 16 bytes per row
+    const RH_GLOBAL u64u* p = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1)) + 2ull * r;
+    v.lo = p[0]; v.hi = p[1];
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t bin_byte(const BinV& v, uint32_t j) {      // byte j of the 16 little-endian value bytes
+  return (uint32_t)((j < 8 ? v.lo >> (8 * j) : v.hi >> (8 * (j - 8))) & 0xFFu);
+}
+__device__ __forceinline__ uint8_t hex_digit(uint32_t x) { return (uint8_t)(x < 10 ? '0' + x : 'a' + (x - 10)); }
+
+// the Avro 1.11 wire forms (mirror of walk.h h_bin): fixed = the N bytes; decimal on bytes = length + minimal big-endian
+// two's complement; decimal on fixed(N) = the low N bytes, big-endian; uuid on string = 36 characters of lower-case
+// 8-4-4-4-12 hex text.  Not a hot path: bytes are produced one at a time.
+template <int MODE, class Ctx>
+__device__ __forceinline__ void e_bin_put(const Ctx& c, ELane& L, const Op op, const BinV v) {
+  if (!L.writes()) return;
+  if (op.flags & F_NULLABLE) {
+    put_branch<MODE>(c, L, !v.valid, (op.flags & F_NULL_FIRST) != 0);
+    if (!v.valid) return;
+  }
+  if (op.a == BN_FIXED) {
+    const uint32_t W = (uint32_t)op.c;
+    put_bytes<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf1)) + (uint64_t)c.row(op.dom) * W, W);
+  } else if (op.a == BN_DEC_FIXED) {
+    const uint32_t N = (uint32_t)op.b;                          // <= 16 (schema gate)
+    if (MODE == M_SIZE) { L.len += N; return; }
+    for (uint32_t j = N; j-- > 0;) put_byte<MODE>(c, L, (uint8_t)bin_byte(v, j));
+  } else if (op.a == BN_DEC_BYTES) {
+    // minimal length: the magnitude bits of v (of ~v when negative) plus a sign bit, in whole bytes, at least one
+    const bool neg = (v.hi >> 63) != 0;
+    const uint64_t mh = neg ? ~v.hi : v.hi, ml = neg ? ~v.lo : v.lo;
+    const uint32_t bits = mh ? 128u - (uint32_t)__builtin_clzll(mh) : (ml ? 64u - (uint32_t)__builtin_clzll(ml) : 0u);
+    const uint32_t nb = bits / 8u + 1u;                         // 1..16
+    put_varint<MODE>(c, L, (int64_t)nb);
+    if (MODE == M_SIZE) { L.len += nb; return; }
+    for (uint32_t j = nb; j-- > 0;) put_byte<MODE>(c, L, (uint8_t)bin_byte(v, j));
+  } else {                                                       // BN_UUID_STR
+    put_varint<MODE>(c, L, 36);
+    if (MODE == M_SIZE) { L.len += 36; return; }
+    for (uint32_t i = 0; i < 16; i++) {
+      const uint32_t b = bin_byte(v, i);
+      put_byte<MODE>(c, L, hex_digit(b >> 4));
+      put_byte<MODE>(c, L, hex_digit(b & 15u));
+      if (i == 3 || i == 5 || i == 7 || i == 9) put_byte<MODE>(c, L, (uint8_t)'-');
+    }
+  }
+}
+
 // ---- writes ----------------------------------------------------------------------------------------------------
 // fast_encode.rs:391-399, 407-455
 template <int MODE, class Ctx>

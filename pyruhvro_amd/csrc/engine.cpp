@@ -1594,7 +1594,7 @@ int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
       image = rh::get_kernel_image(*s->cs, true, &ehit, true);       // and the Arrow -> Avro pair
       if (image.empty()) throw std::runtime_error("encode kernel image empty");
     } else {
-      ehit = true;                                                   // decode-only schema (N4 types)
+      ehit = true;                                                   // a schema rh_encode does not take
     }
     if (cached) *cached = (hit && ehit) ? 1 : 0;
     return RH_OK;
@@ -1708,6 +1708,8 @@ struct EncodeBinder {
         if (t->kind == rh::AV_DATE) ok = fmt == "tdD";
         if (t->kind == rh::AV_TS_MILLIS) ok = fmt.rfind("tsm:", 0) == 0;
         if (t->kind == rh::AV_TS_MICROS) ok = fmt.rfind("tsu:", 0) == 0;
+        if (t->kind == rh::AV_TIME_MILLIS) ok = fmt == "ttm";
+        if (t->kind == rh::AV_TIME_MICROS) ok = fmt == "ttu";
         if (!ok || fa->n_buffers < 2 || (len > 0 && !fa->buffers[1])) throw EncodeError("fast_encode: arrow array downcast failed");
         InBuf& v = in[n.buf_main];
         if (n.fixed == rh::FK_BOOL) {
@@ -1723,9 +1725,19 @@ struct EncodeBinder {
         if (n.nullable) validity(n.buf_validity, fa, off, len);
         return;
       }
+      case rh::NK_BIN: {              // FixedSizeBinary(N) / Decimal128 values, `bin_width` bytes per row
+        const std::string want = t->kind == rh::AV_DECIMAL ? "d:" + std::to_string(t->precision) + "," + std::to_string(t->scale)
+                                                           : "w:" + std::to_string(n.bin_width);
+        if (fmt != want || fa->n_buffers < 2 || (len > 0 && !fa->buffers[1])) throw EncodeError("fast_encode: arrow array downcast failed");
+        InBuf& v = in[n.buf_main];
+        v.host = len ? (const uint8_t*)fa->buffers[1] + (uint64_t)off * (uint64_t)n.bin_width : nullptr;
+        v.bytes = (uint64_t)len * (uint64_t)n.bin_width;
+        if (n.nullable) validity(n.buf_validity, fa, off, len);
+        return;
+      }
       case rh::NK_STRING:
       case rh::NK_ENUM: {
-        if (fmt != "u" || fa->n_buffers < 3) throw EncodeError("fast_encode: arrow array downcast failed");
+        if (fmt != (t->kind == rh::AV_BYTES ? "z" : "u") || fa->n_buffers < 3) throw EncodeError("fast_encode: arrow array downcast failed");
         if (fa->buffers[1]) {           // an empty array may come without an offsets buffer
           const int32_t* offs = (const int32_t*)fa->buffers[1] + off;
           in[n.buf_main].host = (const uint8_t*)offs;

@@ -501,7 +501,6 @@ struct Builder {
         cs.nodes[id].buf_validity = bv;
         cs.nodes[id].buf_main = bm;
         if ((uint32_t)width > cs.max_row_bytes) cs.max_row_bytes = (uint32_t)width;
-        cs.encode_unsupported = "fixed / decimal / uuid";
         Op o = mk(OP_BIN);
         o.flags = (nullable ? F_NULLABLE : 0) | (null_first ? F_NULL_FIRST : 0) | (can_null ? F_CAN_NULL : 0);
         o.dom = cx.dom; o.a = sub; o.b = wire; o.c = width; o.buf0 = bv; o.buf1 = bm; o.node = id;
@@ -509,11 +508,9 @@ struct Builder {
         return id;
       }
       case AV_BYTES:
-        cs.encode_unsupported = "bytes";
         return string_leaf(NK_STRING, nullable, null_first, cx, nullptr);
       case AV_INT: case AV_DATE: case AV_LONG: case AV_TS_MILLIS: case AV_TS_MICROS: case AV_TIME_MILLIS: case AV_TIME_MICROS:
       case AV_FLOAT: case AV_DOUBLE: case AV_BOOLEAN: {
-        if (t.kind == AV_TIME_MILLIS || t.kind == AV_TIME_MICROS) cs.encode_unsupported = "time-millis / time-micros";
         int id = new_node(NK_FIXED);
         DecNode& n = cs.nodes[id];
         n.fixed = (t.kind == AV_INT || t.kind == AV_DATE || t.kind == AV_TIME_MILLIS) ? FK_I32

@@ -26,7 +26,7 @@ enum AvroKind {
   AV_NULL, AV_BOOLEAN, AV_INT, AV_LONG, AV_FLOAT, AV_DOUBLE, AV_BYTES, AV_STRING,
   AV_RECORD, AV_ENUM, AV_ARRAY, AV_MAP, AV_UNION, AV_FIXED,
   AV_DATE, AV_TS_MILLIS, AV_TS_MICROS,
-  AV_TIME_MILLIS, AV_TIME_MICROS, AV_DECIMAL, AV_UUID,   // SURVEY 8f N4 (with AV_BYTES / AV_FIXED): GPU decode only
+  AV_TIME_MILLIS, AV_TIME_MICROS, AV_DECIMAL, AV_UUID,   // SURVEY 8f N4 (with AV_BYTES / AV_FIXED)
   AV_OTHER_LOGICAL,   // duration, local-timestamp-*, timestamp-nanos (no Arrow mapping in the reference: schema_translate.rs:144)
   AV_REF,
 };
@@ -105,7 +105,7 @@ struct CompiledSchema {
   int list_depth = 0;
   uint32_t min_record_bytes = 0;
   uint32_t max_row_bytes = 16;      // widest fixed-width value of one row (bounds the 32-bit in-buffer offsets of the specialised kernels)
-  std::string encode_unsupported;   // non-empty: why rh_encode does not take this schema (N4 types are decode-only)
+  std::string encode_unsupported;   // non-empty: why rh_encode does not take this schema (no such schema today)
 };
 
 // Throws SchemaError.  `json` need not be NUL-terminated.

@@ -32,7 +32,7 @@ def known_schemas() -> List[str]:
         out += cases.encode_extra_schemas()
         import random_cases
         out += [random_cases.random_schema(seed) for seed in range(random_cases.PREBUILT_SEEDS)]
-        import test_n4_types                      # SURVEY 8f N4 schemas (decode-only: no encode pair is built)
+        import test_n4_types                      # SURVEY 8f N4 schemas
         out.append(test_n4_types.SCHEMA)
         g = json.load(open(os.path.join(root, "tests", "golden", "reference_vectors.json")))
         out += [json.dumps(s) for s in g["schemas"].values()]

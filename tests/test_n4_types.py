@@ -16,7 +16,7 @@ import pytest
 from arrow_compare import assert_batches_identical
 from avrogen.encoder import Branch, Unscaled, UuidText, to_datum, zigzag
 from oracle import avro_schema as S
-from oracle import py_walker
+from oracle import py_encoder, py_walker
 
 import pyruhvro_amd as P
 from pyruhvro_amd import cabi
@@ -130,10 +130,38 @@ def test_specification_known_answers_pin_the_oracle():
             py_walker.decode([bad], js, extended=True)
 
 
-def test_encode_direction_says_no_clearly():
-    rb = pa.RecordBatch.from_arrays([pa.array([b"x"], pa.binary())], names=["a"])
-    with pytest.raises(ValueError, match="outside the GPU encode path"):
-        P.serialize_record_batch(rb, '{"type":"record","name":"x","fields":[{"name":"a","type":"bytes"}]}', 1)
+def test_encode_oracle_writes_the_specification_wire_forms():
+    """The encode side of N4 (also beyond the reference): the oracle encoder against literal bytes, and
+    decode(encode(x)) == x over the generator's rows (minimal decimals and canonical uuid text re-encode byte for byte)."""
+    js = json.dumps({"type": "record", "name": "K", "fields": [
+        {"name": "d", "type": {"type": "bytes", "logicalType": "decimal", "precision": 10, "scale": 2}},
+        {"name": "df", "type": F("D2", 2, logicalType="decimal", precision=4, scale=1)},
+        {"name": "b", "type": "bytes"}, {"name": "f", "type": F("F3", 3)},
+        {"name": "u", "type": {"type": "string", "logicalType": "uuid"}},
+        {"name": "uf", "type": F("U16", 16, logicalType="uuid")},
+        {"name": "tm", "type": {"type": "int", "logicalType": "time-millis"}},
+        {"name": "tu", "type": {"type": "long", "logicalType": "time-micros"}}]})
+    D = decimal.Decimal
+    rb = pa.RecordBatch.from_arrays([
+        pa.array([D("12.34"), D("-0.01"), D("0.00"), D("1.27"), D("1.28"), D("-1.28"), D("-1.29")], pa.decimal128(10, 2)),
+        pa.array([D("-12.3"), D("0.0"), D("99.9"), D("-0.1"), D("0.1"), D("1.0"), D("-1.0")], pa.decimal128(4, 1)),
+        pa.array([b"\x00\xff\x10", b"", b"a", b"bc", b"d" * 40, b"e", b"f"], pa.binary()),
+        pa.array([b"abc", b"\x00\x01\x02", b"xyz", b"123", b"456", b"789", b"000"], pa.binary(3)),
+        pa.array([UUID_BYTES] * 7, pa.binary(16)), pa.array([UUID_BYTES[::-1]] * 7, pa.binary(16)),
+        pa.array([3_723_004, 0, 1, 2, 3, 4, 86_399_999], pa.time32("ms")),
+        pa.array([86_399_999_999, 1, 0, 5, 6, 7, 8], pa.time64("us"))], names=["d", "df", "b", "f", "u", "uf", "tm", "tu"])
+    out = [x for a in py_encoder.serialize_record_batch(rb, js, 2, extended=True) for x in a.to_pylist()]
+    assert out[0] == (bytes.fromhex("04" "04d2") + bytes.fromhex("ff85") + bytes.fromhex("06" "00ff10") + b"abc" + bytes([72]) + UUID.encode()
+                      + UUID_BYTES[::-1] + zigzag(3_723_004) + zigzag(86_399_999_999))
+    assert out[1][:4] == bytes.fromhex("02" "ff" "0000")          # -1 is one byte, 0 on fixed(2) is two
+    assert [o[:3] for o in out[2:7]] == [bytes.fromhex("0200" "03"), bytes.fromhex("027f" "ff"), bytes.fromhex("040080"),
+                                         bytes.fromhex("0280" "00"), bytes.fromhex("04ff7f")]      # d = 0, 127, 128, -128, -129 (+ the first byte of df)
+    assert py_walker.decode(out, js, extended=True).to_pylist() == rb.to_pylist()
+    recs = _records(300)
+    batch = py_walker.decode(recs, SCHEMA, extended=True)
+    enc = [x for a in py_encoder.serialize_record_batch(batch, SCHEMA, 4, extended=True) for x in a.to_pylist()]
+    assert py_walker.decode(enc, SCHEMA, extended=True).equals(batch)
+    assert sum(a == b for a, b in zip(enc, recs)) > 60            # the rows whose decimals / uuid text were canonical already
 
 
 # ---------------------------------------------------------------------------------------------------- GPU
@@ -168,6 +196,33 @@ def test_gpu_matches_the_specification_oracle(n, k, kernel):
             assert_batches_identical(g, e)
     finally:
         P.set_devices(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1, 1), (257, 3), (3000, 8)])
+def test_gpu_encode_matches_the_oracle_encoder_and_round_trips(n, k, kernel):
+    """Arrow -> Avro for the N4 types on the GPU (rh_encode, both kernel forms): byte for byte the oracle encoder's
+    datums, and back through the GPU decoder to the batch it started from; sliced input; wrong Arrow types refused."""
+    recs = _records(n)
+    batch = py_walker.decode(recs, SCHEMA, extended=True)
+    got = P.serialize_record_batch(batch, SCHEMA, k)
+    exp = py_encoder.serialize_record_batch(batch, SCHEMA, k, extended=True)
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g.type == pa.binary() and g.equals(e)
+    datums = [x for a in got for x in a.to_pylist()]
+    back = P.deserialize_array_threaded(datums, SCHEMA, 1)[0]
+    assert_batches_identical(back, batch)
+    if n > 100:
+        sl = batch.slice(37, n - 50)
+        for g, e in zip(P.serialize_record_batch(sl, SCHEMA, 2), py_encoder.serialize_record_batch(sl, SCHEMA, 2, extended=True)):
+            assert g.equals(e)
+        js = '{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}'
+        for body, arr in ((json.dumps(F("q", 4)), pa.array([b"abc"], pa.binary(3))),
+                          ('{"type":"bytes","logicalType":"decimal","precision":9,"scale":2}', pa.array([decimal.Decimal("1.5")], pa.decimal128(9, 1))),
+                          ('"bytes"', pa.array(["s"])), ('{"type":"int","logicalType":"time-millis"}', pa.array([1], pa.int32()))):
+            with pytest.raises(ValueError, match="arrow array downcast failed"):
+                P.serialize_record_batch(pa.RecordBatch.from_arrays([arr], names=["a"]), js % body, 1)
 
 
 @pytest.mark.gpu

@@ -37,8 +37,7 @@ HOST_WORKER = textwrap.dedent("""
         assert L.rh_schema_export(h, C.byref(cs)) == 0
         pa.DataType._import_from_c(C.addressof(cs))          # pyarrow calls our release callback
         p = L.rh_schema_kernel_source(h); assert p; L.rh_free_string(p)
-        p = L.rh_schema_encode_kernel_source(h)              # NULL for the decode-only (N4) schemas
-        if p: L.rh_free_string(p)
+        p = L.rh_schema_encode_kernel_source(h); assert p; L.rh_free_string(p)
         L.rh_schema_free(h); n += 1
     assert n > 50
     for bad in ("{", '{"type":"record","name":"B","fields":[{"name":"b","type":"bytes_typo"}]}', '"string"', ""):
