@@ -30,6 +30,7 @@ def known_schemas() -> List[str]:
             out.append(c[1])
         out.append(cases.logical_case()[0])
         out += cases.encode_extra_schemas()
+        out.append(cases.long_string_case(1)[0])
         import random_cases
         out += [random_cases.random_schema(seed) for seed in range(random_cases.PREBUILT_SEEDS)]
         import test_n4_types                      # SURVEY 8f N4 schemas

@@ -270,3 +270,34 @@ ENC_LONG_ENUM_SCHEMA = json.dumps({"type": "record", "name": "r", "fields": [
 
 def encode_extra_schemas():
     return [ENC_WINDOW_SCHEMA, ENC_VALIDITY_SCHEMA, ENC_LONG_ENUM_SCHEMA]
+
+
+def long_string_case(n=1500, seed=5):
+    """Strings of 0..3000 bytes at the top level, inside a nullable record, in an array and as map keys / values:
+    wave spans from a few bytes to far beyond any staging area, so columns take the staged AND the per-lane path."""
+    import random
+    import json
+    s = json.dumps({"type": "record", "name": "LS", "fields": [
+        {"name": "a", "type": "string"},
+        {"name": "b", "type": ["null", "string"]},
+        {"name": "r", "type": ["null", {"type": "record", "name": "RR", "fields": [
+            {"name": "x", "type": "string"}, {"name": "y", "type": ["string", "null"]}]}]},
+        {"name": "l", "type": {"type": "array", "items": "string"}},
+        {"name": "m", "type": {"type": "map", "values": ["null", "string"]}},
+        {"name": "ll", "type": {"type": "array", "items": {"type": "array", "items": "string"}}},
+        {"name": "z", "type": "string"}]})
+    r = random.Random(seed)
+
+    def st(big=False):
+        k = r.random()
+        ln = 0 if k < 0.15 else r.randint(1, 7) if k < 0.5 else r.randint(8, 40) if k < 0.93 else r.randint(41, 3000 if big else 300)
+        return "".join(chr(r.randint(33, 126)) for _ in range(ln))
+    vals = []
+    for i in range(n):
+        vals.append({"a": st(i % 97 == 0), "b": None if r.random() < 0.4 else st(),
+                     "r": None if r.random() < 0.3 else {"x": st(), "y": None if r.random() < 0.5 else st()},
+                     "l": [st() for _ in range(r.choice([0, 0, 1, 2, 5]))],
+                     "m": {f"k{j}{st()[:6]}": (None if r.random() < 0.3 else st()) for j in range(r.choice([0, 1, 3]))},
+                     "ll": [[st() for _ in range(r.choice([0, 1, 3]))] for _ in range(r.choice([0, 1, 2]))],
+                     "z": st()})
+    return s, _enc(s, vals)
