@@ -775,6 +775,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     uint32_t per = stage_pref;
     if ((uint64_t)lds_bytes + (uint64_t)per * nw + 64 > lds_cap) per = lds_bytes + 64 < lds_cap ? (uint32_t)((lds_cap - lds_bytes - 64) / nw) & ~15u : 0u;
     P.stage_off = lds_bytes;
+    P.stage_avg_max = (uint32_t)env_long("RUHVRO_HIP_STAGE_AVG_MAX", 0, 0, 1 << 20);
     P.stage_bytes = per;
     stage_total = per ? per * nw + 64 : 0;   // + slack: stage_put ORs zero up to 12 bytes past a string's last dword
   }

@@ -190,6 +190,7 @@ struct KParams {
   // specialised emit kernel: per-wave LDS staging areas of the wave-cooperative string stores (walk.h stage_put)
   uint32_t stage_off;        // byte offset of wave 0's area from the start of the workgroup's dynamic LDS
   uint32_t stage_bytes;      // bytes per wave (multiple of 16), 0 = every string is copied per lane
+  uint32_t stage_avg_max;    // a column is staged only when its strings average at most this many bytes (0 = any length)
 };
 
 }  // namespace rh

@@ -258,13 +258,19 @@ __device__ __forceinline__ void stage_put(RH_LDS uint8_t* stg, uint32_t sd, cons
     v[2] = __builtin_amdgcn_alignbyte(n3, n2, sh);
     v[3] = __builtin_amdgcn_alignbyte(n4, n3, sh);
     prev = n4;
+    if (__all(rem8 >= 128u)) {                         // every string of the wave covers this round's four dwords: no end masks
+      v[0] &= lomask;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const uint32_t t = __builtin_elementwise_sub_sat(rem8, 32u * (uint32_t)i);   // bits of the string from this dword on
-      const uint32_t cut = __builtin_elementwise_sub_sat(32u, t);                  // 0 inside, 32 past the end
-      uint32_t m = (uint32_t)(0xFFFFFFFFull >> cut);
-      if (i == 0) m &= lomask;
-      __hip_atomic_fetch_or(d + i, v[i] & m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      for (int i = 0; i < 4; i++) __hip_atomic_fetch_or(d + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t t = __builtin_elementwise_sub_sat(rem8, 32u * (uint32_t)i);   // bits of the string from this dword on
+        const uint32_t cut = __builtin_elementwise_sub_sat(32u, t);                  // 0 inside, 32 past the end
+        uint32_t m = (uint32_t)(0xFFFFFFFFull >> cut);
+        if (i == 0) m &= lomask;
+        __hip_atomic_fetch_or(d + i, v[i] & m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
     lomask = 0xFFFFFFFFu;
     rem8 = __builtin_elementwise_sub_sat(rem8, 128u);
