@@ -755,7 +755,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
   const uint64_t payload = geo ? geo->payload_bytes : data_len;
   const uint64_t avg = n ? payload / n + 1 : 16;
-  // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD, RUHVRO_HIP_STAGE_BYTES)
+  // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD)
   const uint64_t win_pct = (uint64_t)env_long("RUHVRO_HIP_WIN_PCT", 115, 100, 400);
   const uint64_t win_pad = (uint64_t)env_long("RUHVRO_HIP_WIN_PAD", 2048, 0, 65536);
   uint64_t win = align_up(avg * tile * win_pct / 100 + win_pad * tile / rh::kBlock, 16);
@@ -764,22 +764,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
   win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
   P.win_bytes = (uint32_t)win;
-  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;   // k_size; k_emit adds the string staging area
-  // per-wave staging areas of the wave-cooperative string stores (specialised emit kernel, walk.h stage_put)
-  uint32_t stage_total = 0;
-  bool has_strings = false;
-  for (const rh::Op& op : cs.prog) has_strings = has_strings || op.code == rh::OP_STRING;
-  if (sk && has_strings) {
-    const uint32_t stage_pref = (uint32_t)env_long("RUHVRO_HIP_STAGE_BYTES", 2816, 0, 32768) & ~15u;
-    const uint32_t nw = (uint32_t)(tile / 64);
-    uint32_t per = stage_pref;
-    if ((uint64_t)lds_bytes + (uint64_t)per * nw + 64 > lds_cap) per = lds_bytes + 64 < lds_cap ? (uint32_t)((lds_cap - lds_bytes - 64) / nw) & ~15u : 0u;
-    P.stage_off = lds_bytes;
-    P.stage_avg_max = (uint32_t)env_long("RUHVRO_HIP_STAGE_AVG_MAX", 0, 0, 1 << 20);
-    P.stage_bytes = per;
-    stage_total = per ? per * nw + 64 : 0;   // + slack: stage_put ORs zero up to 12 bytes past a string's last dword
-  }
-
+  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;
   // optional in-kernel phase timing of the specialised kernels (RUHVRO_HIP_PROFILE=1)
   static const bool profile = [] { const char* e = std::getenv("RUHVRO_HIP_PROFILE"); return e && *e && *e != '0'; }();
   Lease prof_buf;
@@ -856,7 +841,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (nbuf > 0 && (child_bitmaps || !offsets_done) &&
         rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
     if (n > 0) {
-      emit_lds = lds_bytes + stage_total;
+      emit_lds = lds_bytes;
       if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4))
              : rh_launch_emit(&P, emit_lds, stream, ev.at(3), ev.at(4)))
         throw HipError("k_emit launch failed");

@@ -35,7 +35,6 @@ namespace rh {
 // --------------------------------------------------------------------------
 struct ICtx {
   static constexpr bool kWide = true;   // 64-bit buffer indexing: any chunk size
-  static constexpr bool kStage = false; // string bytes are copied per lane (the specialised kernels stage them per wave)
   uint32_t* cnt;             // LDS [K][256]
   uint32_t* rem;             // LDS [depth][256]
   uint32_t* nullcnt;         // LDS [nnodes]

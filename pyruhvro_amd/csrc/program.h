@@ -187,10 +187,6 @@ struct KParams {
   uint16_t* lanecnt;         // [K][nblocks*256] per-record counters, saturated at 0xFFFF
   uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
-  // specialised emit kernel: per-wave LDS staging areas of the wave-cooperative string stores (walk.h stage_put)
-  uint32_t stage_off;        // byte offset of wave 0's area from the start of the workgroup's dynamic LDS
-  uint32_t stage_bytes;      // bytes per wave (multiple of 16), 0 = every string is copied per lane
-  uint32_t stage_avg_max;    // a column is staged only when its strings average at most this many bytes (0 = any length)
 };
 
 }  // namespace rh

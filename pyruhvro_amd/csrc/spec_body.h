@@ -96,74 +96,6 @@ struct SCtx {
   __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
     if (lane == 0 && wave_live) st_global<uint64_t, kWide>(this->buf(buf), lrow >> 6, m);
   }
-  // ---- staged string stores (walk.h stage_put): this wave's LDS staging area ---------------------------------
-  // Columns are lent space stack-wise: a string column of domain 0 for the duration of its own field, the string
-  // columns inside a top-level array / map from the list's begin to its end (a lane's items are consecutive bytes
-  // of the column, so the wave's span is complete only then).  A column whose span does not fit what is left takes
-  // the per-lane copy (copy_bytes): the decision is wave-uniform and known up front from the size pass's counters.
-#ifdef RH_V_NOSTAGE
-  static constexpr bool kStage = false;
-#else
-  static constexpr bool kStage = true;
-#endif
-  static constexpr uint32_t kNoStage = 1u;            // not a possible bias (biases are multiples of 16)
-  RH_LDS uint8_t* stg;
-  uint32_t stg_cap;                                   // bytes of the area (multiple of 16; 0 = none), wave-uniform
-  mutable uint32_t stg_used;                          // bytes lent right now, wave-uniform
-  mutable uint32_t stg_bias[K1];                      // staged column k: buffer byte D sits at staging byte D + stg_bias[k]
-  mutable uint32_t stg_ws[K1];                        // ... and the wave's span of the column starts at buffer byte stg_ws[k]
-  mutable uint32_t wtotal[K1];                        // this wave's byte / row total per counter (wave-uniform; from the tile scan)
-  uint32_t stage_avg_max;                             // stage a column only when its strings average at most this many bytes (0 = any)
-  __device__ __forceinline__ static uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-  __device__ __forceinline__ RH_LDS uint8_t* stage() const { return stg; }
-  __device__ __forceinline__ bool staged(int k) const { return stg_bias[k] != kNoStage; }
-  __device__ __forceinline__ uint32_t stage_bias(int k) const { return stg_bias[k]; }
-  // called by every lane of the wave, before the column's first byte is written
-  // `rows`: how many strings the span holds at most (64 for a column of domain 0, the wave's child rows otherwise).
-  // Long strings are cheaper to copy per lane (16 bytes per store and per four v_alignbyte, no masks) than to stage
-  // (five VALU instructions per dword); short ones fall into many length classes of two stores each -- those are staged.
-  __device__ __forceinline__ void stage_begin(int k, uint32_t rows = 64u) const {
-    const uint32_t T = wtotal[k];
-    const uint32_t ws = rfl(cnt[k]) + rfl(gb[k]);     // lane 0's exclusive prefix = first byte of the wave's span
-    const uint32_t need = ((ws & 15u) + T + 15u) & ~15u;
-    const bool ok = T != 0 && stg_used + need <= stg_cap && (stage_avg_max == 0 || T <= rows * stage_avg_max);
-    stg_bias[k] = ok ? stg_used - (ws & ~15u) : kNoStage;
-    stg_ws[k] = ws;
-    stg_used += ok ? need : 0u;
-  }
-  // called by every lane of the wave, after the column's last byte: aligned 16-byte stores for the chunks the wave owns
-  // alone, single bytes (one instruction) for the partial chunks at the two ends, staging area zeroed again
-  __device__ __forceinline__ void stage_flush(int k, int bufid) const {
-    if (stg_bias[k] == kNoStage) return;
-    const uint32_t T = wtotal[k];
-    const uint32_t ws = stg_ws[k];
-    const uint32_t a0 = ws & 15u, end = a0 + T, nch = (end + 15u) >> 4, dbase = ws & ~15u;
-    RH_LDS uint8_t* sb = stg + (stg_bias[k] + dbase);
-    void* dst = this->buf(bufid);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const bool headpart = a0 != 0 || end < 16u;
-    const bool tailpart = (end & 15u) != 0 && nch > 1;
-    // both LDS reads of the first round are requested before either is waited for
-    const uint32_t which = lane >> 4, b = lane & 15u;
-    const uint32_t pos = (which ? nch - 1 : 0u) * 16u + b;
-    const bool on = lane < 32u && (which ? tailpart : headpart) && pos >= a0 && pos < end;
-    uint32_t byte = 0;
-    if (on) byte = sb[pos];
-    v4w z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-    for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
-      const uint32_t ch = c0 + lane;
-      if (ch < nch) {
-        RH_LDS v4w* sp = reinterpret_cast<RH_LDS v4w*>(sb + 16u * ch);
-        const v4w x = *sp;
-        *sp = z;
-        if (16u * ch >= a0 && 16u * ch + 16u <= end) st_at<v4w, kWide>(dst, dbase + 16u * ch, x);
-      }
-    }
-    if (on) st_at<uint8_t, kWide>(dst, dbase + pos, (uint8_t)byte);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    stg_used -= nch * 16u;
-    stg_bias[k] = kNoStage;
-  }
   uint32_t* bm;                                       // LDS [NBM][kBmWords]
   __device__ __forceinline__ void set_bit(int buf, int dom, uint32_t row) const {
     if constexpr (S::NBM > 0) {
@@ -224,11 +156,8 @@ template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
   static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
-  static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.stg_bias[k] = SCtx<S>::kNoStage; c.stg_ws[k] = 0; });
   c.nullcnt = s.nullcnt; c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
-  static_for<0, SCtx<S>::K1>([&](auto ik) { c.wtotal[decltype(ik)::value] = 0; });
-  c.stg = nullptr; c.stg_cap = 0; c.stg_used = 0; c.stage_avg_max = P.stage_avg_max;
 }
 
 // --------------------------------------------------------------------------
@@ -351,7 +280,6 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       const uint32_t v = c.cnt[k];
       const uint32_t incl = wave_incl_scan(v, lane);
       if (lane == 63) s.wtot[k * NW + wave] = incl;
-      c.wtotal[k] = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       c.cnt[k] = incl - v;
     });
     RH_MARK(4);
@@ -370,14 +298,6 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(6);
   lane_init_from(L, g, o0, o1, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-  if constexpr (SCtx<S>::kStage) {   // this wave's string staging area behind the window, zeroed (walk.h stage_put ORs into it)
-    if (fits && P.stage_bytes) {
-      c.stg = to_lds(smem) + (P.stage_off + wave * P.stage_bytes);
-      c.stg_cap = P.stage_bytes;
-      v4w z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-      for (uint32_t i = lane * 16u; i < P.stage_bytes; i += 1024u) *reinterpret_cast<RH_LDS v4w*>(c.stg + i) = z;
-    }
-  }
   if (careful) {
     spec_run_walk<S, true, true>(P, c, s.win, L, fits, wb16);
   } else {

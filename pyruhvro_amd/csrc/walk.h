@@ -62,8 +62,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // Global memory has no such cliff (tools/gmemalign.hip), so GlobalSrc reads unaligned directly.
 // --------------------------------------------------------------------------
 struct LdsSrc {
-  static constexpr bool kLds = true;
-  const uint8_t* w;   // LDS window, 16-byte aligned; >= 12 readable bytes past the last record (and >= 16 in front)
+  const uint8_t* w;   // LDS window, 16-byte aligned; >= 12 readable bytes past the last record
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return w[p]; }
   // 8 bytes at any byte position: three aligned dwords (ds_read2_b32 + ds_read_b32), two v_alignbyte
   __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
@@ -103,7 +102,6 @@ struct LdsSrc {
 };
 
 struct GlobalSrc {
-  static constexpr bool kLds = false;
   const uint8_t* g;   // payload + window base
   uint64_t lim;       // readable bytes from g
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return g[p]; }
@@ -216,68 +214,6 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
 template <class D>
 __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len) {
   for (uint32_t j = 0; j < len; j++) d[j] = s[j];
-}
-
-// --------------------------------------------------------------------------
-// Wave-cooperative string stores (specialised emit kernel, DESIGN.md "staged string stores").
-//
-// The strings a wavefront writes into one Utf8 / Binary data buffer form ONE contiguous byte span of that buffer
-// (neighbouring lanes own neighbouring rows; a lane's list items are consecutive).  Per-lane copies cost the CU's
-// vector-memory path one instruction per 4..16 bytes per length class (60 of the 92 stores per wave on the benchmark
-// schema, tools/storecost.hip: 17..65 cycles each whatever the number of active lanes).  Instead every lane ORs its
-// bytes into a zeroed per-wave LDS staging area laid out congruent (mod 16) to the destination -- aligned dwords,
-// funnelled into place with v_alignbyte straight from the window, first / last dword masked -- and the wave then
-// flushes the span with aligned 16-byte stores (1 KiB per instruction); the at most two partial 16-byte chunks at the
-// ends of the span, which neighbouring waves share, go out as single bytes in ONE more instruction.
-// A wave's DS instructions execute in order, so no barrier is involved.
-// --------------------------------------------------------------------------
-#define RH_LDS __attribute__((address_space(3)))
-__device__ __forceinline__ RH_LDS uint8_t* to_lds(const void* p) {   // p points into the workgroup's LDS
-  return (RH_LDS uint8_t*)const_cast<uint8_t*>(static_cast<const uint8_t*>(p));
-}
-
-// OR `len` bytes window[sp..] into the staging area at byte position sd (any alignment on both sides), four aligned
-// dwords a round: window dwords are requested together (one LDS round trip per 16 bytes), funnelled to the staging
-// area's alignment, and every dword is masked to the bytes the string owns -- a dword past the string's end ORs
-// zero, so there is no per-dword predicate (the areas are followed by 64 bytes of slack).  len > 0.
-__device__ __forceinline__ void stage_put(RH_LDS uint8_t* stg, uint32_t sd, const uint8_t* win, uint32_t sp, uint32_t len) {
-  const uint32_t a = sd & 3u;
-  const int32_t p = (int32_t)sp - (int32_t)a;          // window byte that lands on byte 0 of the first staging dword
-  const uint32_t sh = (uint32_t)p & 3u;
-  const RH_LDS uint32_t* q = reinterpret_cast<const RH_LDS uint32_t*>(to_lds(win) + (p & ~3));
-  RH_LDS uint32_t* d = reinterpret_cast<RH_LDS uint32_t*>(stg + (sd & ~3u));
-  const uint32_t e = a + len;                          // end of the string, in bytes from the first staging dword
-  uint32_t rem8 = e * 8u;                              // bits from the current dword's start to the string's end
-  uint32_t prev = q[0];
-  uint32_t lomask = 0xFFFFFFFFu << (8u * a);           // the first dword starts a bytes in
-  for (;;) {
-    const uint32_t n1 = q[1], n2 = q[2], n3 = q[3], n4 = q[4];
-    uint32_t v[4];
-    v[0] = __builtin_amdgcn_alignbyte(n1, prev, sh);
-    v[1] = __builtin_amdgcn_alignbyte(n2, n1, sh);
-    v[2] = __builtin_amdgcn_alignbyte(n3, n2, sh);
-    v[3] = __builtin_amdgcn_alignbyte(n4, n3, sh);
-    prev = n4;
-    if (__all(rem8 >= 128u)) {                         // every string of the wave covers this round's four dwords: no end masks
-      v[0] &= lomask;
-#pragma unroll
-      for (int i = 0; i < 4; i++) __hip_atomic_fetch_or(d + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const uint32_t t = __builtin_elementwise_sub_sat(rem8, 32u * (uint32_t)i);   // bits of the string from this dword on
-        const uint32_t cut = __builtin_elementwise_sub_sat(32u, t);                  // 0 inside, 32 past the end
-        uint32_t m = (uint32_t)(0xFFFFFFFFull >> cut);
-        if (i == 0) m &= lomask;
-        __hip_atomic_fetch_or(d + i, v[i] & m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-    }
-    lomask = 0xFFFFFFFFu;
-    rem8 = __builtin_elementwise_sub_sat(rem8, 128u);
-    if (rem8 == 0) break;                              // per lane: lanes with longer strings go on
-    q += 4;
-    d += 4;
-  }
 }
 
 // --------------------------------------------------------------------------
@@ -585,8 +521,6 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   uint32_t row = 0;
   if (EMIT) {
     row = row_of(c, op.dom);
-    // rows of domain 0: the wave's span of this column is written right here (list columns: by the enclosing list)
-    if constexpr (Ctx::kStage && Src::kLds) { if (op.code == OP_STRING && op.dom == 0) c.stage_begin(op.a); }
     if (act) {
       const uint32_t gb = c.gbase(op.a);
       st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row + 1, gb + o + len);   // offsets repeat under nulls
@@ -596,19 +530,13 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
         // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
         // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
         if (op.code == OP_STRING) {
-          if constexpr (Ctx::kStage && Src::kLds) {
-            if (c.staged(op.a)) stage_put(c.stage(), gb + o + c.stage_bias(op.a), src.w, spos, len);
-            else copy_bytes<Ctx::kWide>(c.buf(op.buf2), (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
-          } else {
-            copy_bytes<Ctx::kWide>(c.buf(op.buf2), (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
-          }
+          copy_bytes<Ctx::kWide>(c.buf(op.buf2), (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
         } else {
           RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
           copy_plain(d, c.sym_data + spos, len);
         }
       }
     }
-    if constexpr (Ctx::kStage && Src::kLds) { if (op.code == OP_STRING && op.dom == 0) c.stage_flush(op.a, op.buf2); }
   }
   bo = o + len;   // len == 0 for every lane that does not carry a value
   put_validity<EMIT>(c, op, act, valid, row);

@@ -318,30 +318,20 @@ def test_full_schema_10m_properties(kernel):
     assert part.equals(got[0].slice(0, 1000))
 
 
-# ---- wave-cooperative string stores of the specialised emit kernel (walk.h stage_put / spec_body.h stage_flush) ----
+def test_long_and_short_strings_everywhere():
+    """Strings of 0..3000 bytes at the top level, inside a nullable record, in arrays, nested arrays and as map keys /
+    values (cases.long_string_case): every length class of the per-lane string copy, wave spans from a few bytes to
+    tens of KB, on both kernel forms."""
+    s, recs = cases.long_string_case()
+    for k in (1, 4):
+        _check(recs, s, k)
 
-@pytest.mark.parametrize("stage_bytes", [0, 32, 256, 1024, 2816, 16384])
-def test_staged_string_stores_any_area_size(stage_bytes, monkeypatch):
-    """The per-wave LDS staging areas of the string stores, from none (every string copied per lane) over areas only
-    some columns of some waves fit into, to areas nothing overflows: always the oracle's buffers."""
-    old = P.set_kernel_mode("specialized")
-    try:
-        monkeypatch.setenv("RUHVRO_HIP_STAGE_BYTES", str(stage_bytes))
-        recs = synth.records("full", 3000, seed=7)
-        _, st = P.deserialize_array_threaded_with_stats(recs, SCHEMAS["full"], 3)
-        monkeypatch.setenv("RUHVRO_HIP_STAGE_BYTES", "0")
-        _, st0 = P.deserialize_array_threaded_with_stats(recs, SCHEMAS["full"], 3)
-        monkeypatch.setenv("RUHVRO_HIP_STAGE_BYTES", str(stage_bytes))
-        assert st["specialized"] == 1
-        assert st["lds_bytes"] - st0["lds_bytes"] == (4 * stage_bytes + 64 if stage_bytes else 0)   # the areas really exist
-        for name, n, k in (("full", 5003, 7), ("cfg3", 3000, 2), ("array_and_map", 2500, 3), ("full", 65, 1)):
-            _check(synth.records(name, n, seed=3), SCHEMAS[name], k)
-        s, recs = cases.long_string_case()
-        for k in (1, 4):
-            _check(recs, s, k)
-        import random_cases
-        for seed in range(0, 40, 3):
-            js, rr = random_cases.random_case(seed, 700)
-            _check(rr, js, 1 + seed % 4)
-    finally:
-        P.set_kernel_mode(old)
+
+@pytest.mark.parametrize("pct,pad", [(100, 0), (103, 64), (400, 65536)])
+def test_any_lds_window_size(pct, pad, monkeypatch):
+    """The LDS input window from tighter than the mean tile (most tiles are then walked from global memory) to far
+    larger than any tile: same buffers (RUHVRO_HIP_WIN_PCT / RUHVRO_HIP_WIN_PAD, read per call)."""
+    monkeypatch.setenv("RUHVRO_HIP_WIN_PCT", str(pct))
+    monkeypatch.setenv("RUHVRO_HIP_WIN_PAD", str(pad))
+    for name, n, k in (("full", 5003, 7), ("cfg3", 3000, 2), ("array_and_map", 2500, 3)):
+        _check(synth.records(name, n, seed=3), SCHEMAS[name], k)
