@@ -16,12 +16,17 @@ N > 1 (BASELINE.json config 5): the SAME seeded 10M-record list, its 8 reference
 collective: records are independent; RCCL carries the barrier, the MAX over rank times and the stats all-gather.
 `--scaling weak` keeps round 1's mode (every rank decodes its own 10M records of the stream).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with three extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   roofline      k_emit (the dominant kernel): algorithmic bytes per launch / its mean launch duration,
-                measured with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM.
+                measured with HIP events on the launch stream inside the timed steps, vs 8 TB/s HBM.  Also the whole
+                path against the same bytes (`path_frac`), the north star's own figure -- HBM READ bandwidth of the two
+                passes together, rocprofv3 FETCH_SIZE of both (stamped file) / their time (`read_GBps`, `read_frac`) --
+                and one sub-object per kernel (`kernels`).
+  config5_projection  (N=1) the step ONE rank of BASELINE config 5 would run when the list is dealt to 2 / 4 / 8 GPUs,
+                measured on this GPU, and the strong-scaling efficiency it implies.  A projection, labelled as one.
   cpu_baseline  the oracle's C restatement of the reference walker ("port"), reference threading shape
-                (serial pack + one thread per chunk, 8 chunks), timed on this box's host cores on a
-                bounded sample of the same workload.  Reported, not targeted.
+                (serial pack + one thread per chunk), timed on this box's host cores on the SAME records, best of 5:
+                with the workload's 8 chunks = 8 threads, and (`wide`) with min(64, cores) chunks.  Reported, not targeted.
   end_to_end    (N=1 only) the same workload through the HOST entry points of the C ABI -- host records in, host
                 Arrow batches out, PCIe both ways included -- so the CPU baseline has a like-for-like neighbour:
                 rh_decode_packed (one packed payload), rh_decode (one slice per record, what the CPython boundary
@@ -39,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 KERNEL = 0                      # rh_opts.flags: 0 auto, 1 generic interpreter, 2 schema-specialised
-STATS_EVERY = 4                 # every 4th timed step carries the kernel timestamps (see run())
+STATS_EVERY = 2                 # every 2nd timed step carries the kernel timestamps (see run())
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     # name: (generator config, records per GPU, num_chunks, description)
@@ -60,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="records of the CPU baseline (0 = the whole workload)")
     ap.add_argument("--direction", default="decode", choices=["decode", "encode"],
                     help="encode = the other direction (SURVEY 8f N1, rh_encode: Arrow -> Avro), a secondary line")
     ap.add_argument("--rows", type=int, default=2_000_000, help="--direction encode: rows of the full schema")
@@ -69,38 +74,52 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def measured_traffic(kernel: str, schema_json: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/hbm_traffic.json, written by scripts/rocpd_summary.py --traffic-json from separate
-    FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied).  The file is stamped with the content
-    hash of the kernels it was measured on: a file from another kernel revision is REFUSED (None), never reported."""
+def stamped_traffic(schema_json: str, encode: bool = False):
+    """Per-kernel HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/hbm_traffic.json / profiles/encode_hbm_traffic.json, written by scripts/rocpd_summary.py --traffic-json
+    from separate FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction applied).  The file is stamped with the
+    content hash of the kernels it was measured on: a file from another kernel revision is REFUSED ({}), never reported."""
     try:
         from pyruhvro_amd import cabi
-        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        if d.get("_kernel_key") != cabi.kernel_key(schema_json):
-            return None
-        return float(d[kernel]["hbm_bytes"])
+        name = "encode_hbm_traffic.json" if encode else "hbm_traffic.json"
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if d.get("_kernel_key") != cabi.kernel_key(schema_json, encode):
+            return {}
+        return {k: v for k, v in d.items() if isinstance(v, dict)}
     except Exception:
-        return None
+        return {}
 
 
 def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int):
-    """Oracle C walker with the reference's threading shape, bounded sample, best of 3."""
+    """Oracle C walker ("port" of ruhvro/src/fast_decode.rs) with the reference's threading shape (serial pack + one task
+    per chunk, ruhvro/src/deserialize.rs:76-121), on the SAME inputs as the GPU leg, best of 5 after a warm-up: once
+    with the workload's own num_chunks (= threads), once with as many chunks as this host has cores (capped at 64) so
+    that the host-in -> host-out neighbour of `end_to_end` is a CPU that was given its cores."""
     from avrogen import fastgen
     from oracle import c_walker
     data, offsets = fastgen.generate(gen_cfg, n_sample)
     cs = c_walker.CompiledSchema(schema_json)
-    c_walker.decode_packed(cs, data, offsets, num_chunks, threaded=True, materialize=False)   # warm-up
-    best = float("inf")
-    for _ in range(3):
-        t = time.perf_counter()
-        c_walker.decode_packed(cs, data, offsets, num_chunks, threaded=True, materialize=False)
-        best = min(best, time.perf_counter() - t)
-    return {
-        "value": n_sample / best, "unit": "records/s", "cores": num_chunks, "kind": "port",
-        "sample": f"{n_sample} records of the same workload, {num_chunks} chunks = {num_chunks} threads "
-                  f"(reference shape: serial pack + one task per chunk), best of 3; host has {os.cpu_count()} cpus",
+
+    def timed(threads):
+        c_walker.decode_packed(cs, data, offsets, threads, threaded=True, materialize=False)   # warm-up
+        best = float("inf")
+        for _ in range(5):
+            t = time.perf_counter()
+            c_walker.decode_packed(cs, data, offsets, threads, threaded=True, materialize=False)
+            best = min(best, time.perf_counter() - t)
+        return n_sample / best
+
+    ncpu = os.cpu_count() or 1
+    wide = max(num_chunks, min(64, ncpu))
+    out = {
+        "value": timed(num_chunks), "unit": "records/s", "cores": num_chunks, "kind": "port",
+        "sample": f"all {n_sample} records of the workload, {num_chunks} chunks = {num_chunks} threads "
+                  f"(reference shape: serial pack + one task per chunk), best of 5; host has {ncpu} cpus",
     }
+    if wide != num_chunks:
+        out["wide"] = {"value": timed(wide), "unit": "records/s", "cores": wide,
+                       "sample": f"same records, {wide} chunks = {wide} threads (what the reference would use with num_chunks={wide}), best of 5"}
+    return out
 
 
 def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sample: int = 2_000_000):
@@ -134,6 +153,10 @@ def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sampl
     out["record_slices"] = best_of(lambda: cabi.decode_slices(ptrs, lens, schema_json, num_chunks, want_stats=True))
     out["record_slices"]["what"] = ("rh_decode: one (pointer, length) per record, gathered into pinned memory per chunk group "
                                     "while earlier groups are on the wire -> host RecordBatches")
+    out["packed_8_logical_shards"] = best_of(lambda: cabi.decode_packed(data, offsets, schema_json, num_chunks, want_stats=True,
+                                                                        devices=[0] * num_chunks))
+    out["packed_8_logical_shards"]["what"] = (f"rh_decode_packed with rh_opts.devices = [0] * {num_chunks}: the in-process multi-GPU driver "
+                                              "(one host thread + stream per shard) on this one GPU")
     m = min(py_sample, n)
     recs = fastgen.split(data[: int(offsets[m])], offsets[: m + 1])
     P.deserialize_array_threaded(recs, schema_json, num_chunks)
@@ -204,6 +227,7 @@ def run(args, make_step=None, backend="nccl"):
     wall = rdist.max_over_ranks(wall, dev)
 
     run.info = info
+    run.step = step
     local = {"records": shard["rows"], "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
              "step_ms": wall * 1e3 / args.steps}
     for k in acc:
@@ -233,15 +257,36 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     data_len = int(offsets[-1])
     info = {"input_bytes": data_len, "output_bytes": 0}
 
+    # every ctypes argument is built once (cabi.PreparedDeviceDecode): a timed step is the C entry point + the free
+    call = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
+                                     device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"])
+
     def step(want_stats=True):
-        r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
-                               device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"],
-                               want_stats=want_stats)
-        info["output_bytes"] = r.output_bytes
-        st = r.stats
-        r.free()
+        h = call.run(want_stats)
+        st = None
+        if want_stats:
+            st = call.stats.as_dict()
+            info["output_bytes"] = call.output_bytes(h)
+        call.free(h)
         return st
 
+    def rank_step(world, rank=0):
+        """The step rank `rank` of `world` would run on BASELINE config 5 (one list, whole reference chunks per GPU):
+        its rows of THIS list, the list's chunk geometry (rh_opts.chunk_rows).  Rank 0's rows are a prefix of the
+        buffers already in HBM."""
+        from pyruhvro_amd import dist as rdist
+        sh = rdist.strong_shard(n, num_chunks, world, rank)
+        assert sh["row_lo"] == 0
+        dl = int(offsets[sh["rows"]])
+
+        c = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), dl, sh["rows"], schema, sh["chunks"],
+                                      device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=sh["chunk_rows"])
+
+        def f():
+            c.free(c.run(False))
+        return f, sh
+
+    step.rank_step = rank_step
     step.keepalive = (d_data, d_off)
     first = step()      # also fills output_bytes
     assert first["records"] == n
@@ -279,6 +324,8 @@ def encode_main(args):
     for key in acc:
         acc[key] /= args.steps
     alg = st["input_bytes"] + total + 4 * (n + k)           # Arrow bytes in + Avro bytes out + i32 offsets out
+    et = stamped_traffic(schema, encode=True).get("rh_espec_emit" if st.get("specialized") else "rh_e_emit")
+    enc_traffic = et["hbm_bytes"] if et and n == 2_000_000 else None      # measured on the 2M-row launch only
     emit_ms = acc["emit_kernel_ms"]
     kern_ms = acc["size_kernel_ms"] + acc["scan_kernel_ms"] + emit_ms
     print(json.dumps({
@@ -292,7 +339,35 @@ def encode_main(args):
                    "kernel_form": "schema-specialised" if st.get("specialized") else "generic interpreter"},
         "roofline": {"bound": "hbm", "kernel": "rh_espec_emit" if st.get("specialized") else "rh_e_emit", "achieved": alg / (emit_ms * 1e-3) / 1e9 if emit_ms else 0.0,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if emit_ms else 0.0,
-                     "traffic": None, "algorithmic_bytes_per_launch": int(alg), "bytes_per_record": alg / n, "avg_launch_ms": emit_ms}}))
+                     "traffic": enc_traffic, "traffic_rows": 2_000_000 if enc_traffic else None,
+                     "algorithmic_bytes_per_launch": int(alg), "bytes_per_record": alg / n, "avg_launch_ms": emit_ms}}))
+
+
+def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int = 40):
+    """BASELINE config 5 without an 8-GPU node: the step ONE rank would run when the same list is dealt to g GPUs
+    (rank 0's chunks of it, the list's chunk geometry via rh_opts.chunk_rows), timed on this GPU like the main loop
+    (calls back to back, one sync at the end).  Ranks are independent (no data-path collective), so the job's step
+    at g GPUs is the slowest rank's step: implied strong-scaling efficiency = (ms_per_step at 1 GPU / g) / that.
+    A PROJECTION from one GPU -- the RCCL barrier and the MAX over ranks of the real run are not in it."""
+    import torch
+    out = {"what": "per-rank step of the 10M-record list over g GPUs, measured on this one GPU; a projection, not an N-GPU run",
+           "ms_per_step_1gpu": ms_per_step_1gpu, "g": {}}
+    for g in (2, 4, 8):
+        if g > num_chunks:
+            continue
+        f, sh = step.rank_step(g)
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) * 1e3 / reps
+        out["g"][str(g)] = {"records_per_rank": sh["rows"], "chunks_per_rank": sh["chunks"], "ms_per_step": ms,
+                            "ideal_ms": ms_per_step_1gpu / g, "implied_efficiency": (ms_per_step_1gpu / g) / ms if ms > 0 else 0.0,
+                            "implied_records_per_s": sh["rows"] * g / (ms * 1e-3) if ms > 0 else 0.0}
+    return out
 
 
 def main(argv=None):
@@ -328,7 +403,39 @@ def main(argv=None):
                 "kernel_ms": {"k_size": r["size_kernel_ms"], "k_scan": r["scan_kernel_ms"], "k_emit": r["emit_kernel_ms"]},
                 "emit_alg_GBps": (r["input_bytes"] + 8 * r["records"] + r["output_bytes"]) / (r["emit_kernel_ms"] * 1e-3) / 1e9
                 if r["emit_kernel_ms"] > 0 else 0.0} for i, r in enumerate(per_rank)]
-    emit_kernel = "rh_spec_emit" if getattr(run, "info", {}).get("specialized") else "rh_k_emit"
+    spec = bool(getattr(run, "info", {}).get("specialized"))
+    emit_kernel = "rh_spec_emit" if spec else "rh_k_emit"
+    size_kernel = "rh_spec_size" if spec else "rh_k_size"
+    shard_whole = args.workload == "full10m" and not args.records
+    # HBM bytes per launch from the stamped PMC passes: only for the launch they were measured on (1 GPU, 10M records)
+    traffic = stamped_traffic(SCHEMAS[gen_cfg]) if world == 1 and shard_whole else {}
+    size_ms, scan_ms = r0["size_kernel_ms"], r0["scan_kernel_ms"]
+    kernels = {}
+    for name, ms, alg in ((size_kernel, size_ms, b_in + 8 * rs["records"]), ("rh_k_scan", scan_ms, 0), (emit_kernel, emit_ms, alg_bytes)):
+        t = traffic.get(name)
+        k = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": int(alg),
+             "alg_GBps": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
+        if t:
+            k.update({"hbm_read_bytes": t["hbm_read_bytes"], "hbm_write_bytes": t["hbm_write_bytes"],
+                      "hbm_read_GBps": t["hbm_read_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                      "hbm_GBps": t["hbm_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
+        kernels[name] = k
+    both_ms = size_ms + emit_ms
+    read_bytes = sum(traffic[k]["hbm_read_bytes"] for k in (size_kernel, emit_kernel)) if size_kernel in traffic and emit_kernel in traffic else None
+    roofline = {"bound": "hbm", "kernel": emit_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic[emit_kernel]["hbm_bytes"] if emit_kernel in traffic else None,
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "bytes_per_record": alg_bytes / max(rs["records"], 1), "avg_launch_ms": emit_ms,
+                "timed_launches": (args.steps + STATS_EVERY - 1) // STATS_EVERY,
+                # the whole path (k_size + k_scan + k_emit) against the same algorithmic bytes, and the north star's own
+                # figure: HBM READ bandwidth of the two passes together (rocprofv3 FETCH_SIZE of both / their time)
+                "path_achieved": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
+                "path_frac": alg_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if path_ms > 0 else 0.0,
+                "read_GBps": read_bytes / (both_ms * 1e-3) / 1e9 if read_bytes and both_ms > 0 else None,
+                "read_frac": read_bytes / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if read_bytes and both_ms > 0 else None,
+                "path_traffic": sum(t["hbm_bytes"] for n_, t in traffic.items() if n_.startswith("rh_")) if traffic else None,
+                "kernels": kernels}
     out = {
         "metric": "Avro records/sec -> Arrow (direct decode, input and output resident in HBM)",
         "value": agg["records_per_s"],
@@ -355,15 +462,12 @@ def main(argv=None):
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
                    "path_kernel_ms": path_ms,
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
-        "roofline": {"bound": "hbm", "kernel": emit_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic(emit_kernel, SCHEMAS[gen_cfg]) if args.workload == "full10m" and args.scaling == "strong" or world == 1 and args.workload == "full10m" else None,
-                     "algorithmic_bytes_per_launch": int(alg_bytes),
-                     "bytes_per_record": alg_bytes / max(rs["records"], 1), "avg_launch_ms": emit_ms,
-                     "timed_launches": (args.steps + STATS_EVERY - 1) // STATS_EVERY},
+        "roofline": roofline,
     }
+    if world == 1 and shard_whole and hasattr(run.step, "rank_step"):
+        out["config5_projection"] = config5_projection(run.step, wall * 1e3 / args.steps, num_chunks)
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
-        out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n), num_chunks)
+        out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n) if args.cpu_sample else n, num_chunks)
     if not args.no_end_to_end and world == 1:
         out["end_to_end"] = end_to_end(gen_cfg, SCHEMAS[gen_cfg], n, num_chunks)
     print(json.dumps(out))

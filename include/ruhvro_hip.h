@@ -167,6 +167,19 @@ int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct A
               uint64_t num_chunks, const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k,
               rh_stats* stats, char** err);
 
+/* Process-wide counters of the engine's rarely taken branches (monotonic; tests read them before and after a call to
+ * prove that the branch they aim at really ran).  Fills out[0..n) with as many of the RH_CTR_* values as fit; returns
+ * RH_CTR_COUNT. */
+enum {
+  RH_CTR_FUSED_CALLS = 0,      /* decode calls that took the single-submission path (device-side arena layout)      */
+  RH_CTR_TWO_SYNC_CALLS = 1,   /* ... that laid the arena out on the host between scan and emit (first call / env)  */
+  RH_CTR_CAPACITY_RETRIES = 2, /* LF_CAPACITY: the arena reserved from the size history was too small, tail re-run  */
+  RH_CTR_WIDE_FALLBACKS = 3,   /* NeedWideIndex: a call re-run on the generic kernels (64-bit in-buffer offsets)    */
+  RH_CTR_OFFSET32_ERRORS = 4,  /* calls refused because a chunk's column exceeds 32-bit Arrow offsets               */
+  RH_CTR_COUNT = 5
+};
+uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
+
 void rh_free_string(char* s);
 int rh_abi_version(void);
 /* Number of visible HIP devices (0 when no GPU / driver); never throws. */

@@ -118,8 +118,21 @@ def lib():
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_device_count.restype = C.c_int
+        L.rh_engine_counters.restype = C.c_uint32
+        L.rh_engine_counters.argtypes = [C.POINTER(C.c_uint64), C.c_uint32]
         _lib = L
     return _lib
+
+
+ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors")
+
+
+def engine_counters() -> dict:
+    """Process-wide counters of the engine's rarely taken branches (rh_engine_counters), by name."""
+    buf = (C.c_uint64 * len(ENGINE_COUNTERS))()
+    n = lib().rh_engine_counters(buf, len(ENGINE_COUNTERS))
+    assert n == len(ENGINE_COUNTERS)
+    return {name: int(buf[i]) for i, name in enumerate(ENGINE_COUNTERS)}
 
 
 def _take_err(err: C.c_char_p) -> str:
@@ -329,3 +342,38 @@ def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_jso
     if rc != RH_OK:
         _raise(rc, err)
     return DeviceResult(out.value, s, st.as_dict())
+
+
+class PreparedDeviceDecode:
+    """One rh_decode_device call with every ctypes argument built ONCE: a loop that repeats the call pays the C entry
+    point only (what a C caller pays), not ~15 us of Python argument marshalling per call -- which is the size of a
+    whole 1M-record call's fixed cost.  run() -> opaque result handle (free it with free()); `stats` is refilled by
+    every run(want_stats=True)."""
+
+    def __init__(self, d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
+                 device: int = -1, stream: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0):
+        self._L = lib()
+        self._schema = Schema.get(schema_json)
+        self._opts, self._keep = make_opts(device, kernel, stream, None, chunk_rows)
+        self.stats = RhStats()
+        self._out = C.c_void_p()
+        self._err = C.c_char_p()
+        self._args = (self._schema.handle, C.c_void_p(d_data), C.c_void_p(d_offsets), C.c_uint64(data_len), C.c_uint64(n),
+                      C.c_uint64(num_chunks), C.byref(self._opts), C.byref(self._out))
+        self._st = C.byref(self.stats)
+        self._e = C.byref(self._err)
+        self._fn = self._L.rh_decode_device
+        self._free = self._L.rh_device_result_free
+
+    def run(self, want_stats: bool = False) -> int:
+        rc = self._fn(*self._args, self._st if want_stats else None, self._e)
+        if rc != RH_OK:
+            _raise(rc, self._err)
+        return self._out.value
+
+    def output_bytes(self, handle: int) -> int:
+        return int(self._L.rh_device_result_output_bytes(handle))
+
+    def free(self, handle: int) -> None:
+        self._free(handle)
+

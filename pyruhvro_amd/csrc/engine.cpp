@@ -42,6 +42,7 @@ extern "C" {
 // start / stop: optional hipEvent_t that receive the kernel's own begin / end timestamps (hipExtLaunchKernelGGL): no
 // separate marker packets in the stream, so timing a call costs it almost nothing
 int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
+int rh_launch_scan_layout(const rh::KParams* P, const rh::LParams* L, void* stream, void* start, void* stop);
 int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
@@ -71,6 +72,9 @@ struct ValueClassError : std::runtime_error {   // data-dependent failures of ot
   using std::runtime_error::runtime_error;
 };
 struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic kernels index that far
+
+std::atomic<uint64_t> g_counters[RH_CTR_COUNT];     // rh_engine_counters (include/ruhvro_hip.h)
+inline void count(int which) { g_counters[which].fetch_add(1, std::memory_order_relaxed); }
 
 #define HIPCHK(expr)                                                                          \
   do {                                                                                        \
@@ -646,6 +650,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   try {
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats, geo);
   } catch (const NeedWideIndex&) {
+    count(RH_CTR_WIDE_FALLBACKS);
     rh_opts o = default_opts();
     if (opts) o = *opts;
     o.flags = RH_KERNEL_GENERIC;
@@ -702,7 +707,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const SpecKernel* sk = nullptr;
   // the specialised kernels address every chunk buffer with 32-bit byte offsets
   // (every chunk buffer below 4 GiB: at most max_row_bytes per row -- 16 unless the schema has a wider fixed)
-  const uint64_t narrow_rows = std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16));
+  // (RUHVRO_HIP_NARROW_ROWS: test hook that lowers the bound so that small inputs take the wide-index fallback)
+  const uint64_t narrow_rows = (uint64_t)env_long("RUHVRO_HIP_NARROW_ROWS",
+                                                  (long)std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16)), 1, 1l << 28);
   const bool narrow_ok = std::max(r.sz, r.rows_last) < narrow_rows;
   if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
     const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
@@ -726,7 +733,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
   const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
   const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
-  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 2ull * K * nblocks * tile : 0), kAlign);
+  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((K + 1) / 2) * nblocks * tile : 0), kAlign);
   hp.mark("setup");
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
@@ -748,7 +755,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
   P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
   P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
-  P.lanecnt = (uint16_t*)(ws.ptr() + o_lcnt);
+  P.lanecnt = (uint32_t*)(ws.ptr() + o_lcnt);
 
   // LDS: fixed part + input window sized from the mean record length (falls back to global reads
   // for workgroups whose 256 records do not fit)
@@ -811,7 +818,10 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     }
     r.data_bytes = totals;
     for (auto t : totals)
-      if (t > 0x7FFFFFFFull) throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
+      if (t > 0x7FFFFFFFull) {
+        count(RH_CTR_OFFSET32_ERRORS);
+        throw DecodeError("offset overflow: a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets");
+      }
     if (sk)
       for (int d = 1; d < cs.ndom; d++)
         for (uint32_t c = 0; c < k; c++)
@@ -869,8 +879,11 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     check_bad(hctrl.ptr());
   };
 
-  static const bool two_sync = [] { const char* e = std::getenv("RUHVRO_HIP_TWO_SYNC"); return e && *e && *e != '0'; }();
-  const double ratio = s->arena_ratio.load();
+  const bool two_sync = env_long("RUHVRO_HIP_TWO_SYNC", 0, 0, 1) != 0;
+  // (RUHVRO_HIP_ARENA_PERMILLE: test hook, the arena is reserved as if the schema's history said that many output
+  //  bytes per 1000 input bytes -- a small value forces the LF_CAPACITY retry)
+  const long ratio_hook = env_long("RUHVRO_HIP_ARENA_PERMILLE", -1, 0, 1000000);
+  const double ratio = ratio_hook >= 0 ? std::max(1e-9, ratio_hook / 1000.0) : s->arena_ratio.load();
   const bool fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
   // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
   // e3..e4 = k_emit
@@ -879,14 +892,16 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
            : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
       throw HipError("k_size launch failed");
-    if (rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
+    // (the single-submission path scans and lays the arena out in ONE launch, below)
+    if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
   } else {
     // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
-    if (sk && n > 0) HIPCHK(hipMemsetAsync(ws.ptr() + o_flag, 0x02, 4ull * nblocks, stream));
+    P.all_careful = 1;
   }
   hp.mark("size+scan_launch");
   const double basis = (double)payload + 64.0 * (double)n;
   if (fused) {
+    count(RH_CTR_FUSED_CALLS);
     const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
     r.arena = Lease(dev_pool(), capacity, device);
     rh::LParams LP;
@@ -895,7 +910,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
     LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
     LP.narrow_rows = narrow_rows;
-    if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
+    if (timed_size ? rh_launch_scan_layout(&P, &LP, stream, ev.at(5), ev.at(2)) : rh_launch_layout(&LP, stream))
+      throw HipError("k_scan / k_layout launch failed");
     launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
     hp.mark("layout+emit_launch");
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
@@ -906,6 +922,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
     const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
     if (lflag & rh::LF_CAPACITY) {
+      count(RH_CTR_CAPACITY_RETRIES);
       r.arena.release();
       exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
     } else {
@@ -914,6 +931,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       if (r.arena_bytes != std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign)) throw HipError("internal error: device and host arena layouts differ");
     }
   } else {
+    count(RH_CTR_TWO_SYNC_CALLS);
     if (n > 0 && K > 0) {
       HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
@@ -1493,6 +1511,11 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
 extern "C" {
 
 int rh_abi_version(void) { return RH_ABI_VERSION; }
+
+uint32_t rh_engine_counters(uint64_t* out, uint32_t n) {
+  for (uint32_t i = 0; i < n && i < (uint32_t)RH_CTR_COUNT; i++) out[i] = g_counters[i].load(std::memory_order_relaxed);
+  return RH_CTR_COUNT;
+}
 
 int rh_device_count(void) {
   int n = 0;

@@ -196,8 +196,17 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) {
 // --------------------------------------------------------------------------
 // k_scan: one workgroup per (counter, chunk)
 // --------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {
-  __shared__ uint32_t wt[4];
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P);
+
+// --------------------------------------------------------------------------
+// k_scan + k_layout in ONE launch (the single-submission path): every workgroup scans its (counter, chunk) segment
+// like rh_k_scan; the workgroup that finishes LAST (ticket in control word [1] high half, zeroed with the control
+// words) lays the arena out from the chunk totals all of them left.  One launch and one inter-kernel gap less per
+// call -- what a 1M-record call is made of (profiles/r03e_*).  Cross-workgroup visibility of the totals: release
+// fence + ticket by the writer, acquire fence by the last workgroup (agent scope; the L2s hold next to nothing dirty
+// here, so the fences are cheap -- unlike in a tile look-back).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void scan_segment(const KParams& P, uint32_t* wt) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t kk = blockIdx.x % (uint32_t)P.K, ch = blockIdx.x / (uint32_t)P.K;
   const uint32_t b0 = ch * P.bpc;
@@ -221,6 +230,11 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {
   if (tid == 0) P.totals[(size_t)kk * P.k + ch] = carry;
 }
 
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {
+  __shared__ uint32_t wt[4];
+  scan_segment(P, wt);
+}
+
 // --------------------------------------------------------------------------
 // k_layout: one workgroup.  Entry e = chunk * nbuf + buf of the [chunk][buf] tables gets its arena slot: an exclusive
 // scan of the slot sizes in table order (each thread owns a contiguous run of entries, the 256 run sums are scanned
@@ -237,9 +251,9 @@ __device__ __forceinline__ uint64_t layout_entry(const LParams& L, uint32_t e, u
   return buf_bytes(d.kind, rows, tot, nullptr, (uint32_t)d.counter);
 }
 
-extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {
-  __shared__ uint64_t run_sum[kBlock];
-  __shared__ uint32_t flags;
+// the layout of one call, by the 256 threads of ONE workgroup (rh_k_layout, or the last workgroup of rh_k_scan_layout)
+__device__ __forceinline__ void layout_body(const LParams& L, uint64_t* run_sum, uint32_t* flags_p) {
+  uint32_t& flags = *flags_p;
   const uint32_t tid = threadIdx.x;
   const uint32_t E = L.k * (uint32_t)L.nbuf;
   const uint32_t per = (E + kBlock - 1) / kBlock;
@@ -275,6 +289,30 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {
     if (L.desc[e % (uint32_t)L.nbuf].kind == BK_OFFSETS) *reinterpret_cast<uint32_t*>(L.arena + off) = 0;
     off += buf_slot_bytes(sz);
   }
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_layout(LParams L) {
+  __shared__ uint64_t run_sum[kBlock];
+  __shared__ uint32_t flags;
+  layout_body(L, run_sum, &flags);
+}
+
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P, LParams L) {
+  __shared__ uint64_t run_sum[kBlock];
+  __shared__ uint32_t wt[4];
+  __shared__ uint32_t flags;
+  __shared__ uint32_t last;
+  scan_segment(P, wt);
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this workgroup's total before its ticket
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(L.ctrl) + 3;
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == gridDim.x - 1 ? 1u : 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // everybody's totals before the layout reads them
+  }
+  __syncthreads();
+  if (!last) return;
+  layout_body(L, run_sum, &flags);
 }
 
 // true when the call must not emit: a malformed record was found by the size pass, or the layout kernel said no
@@ -370,6 +408,12 @@ extern "C" int rh_launch_scan(const rh::KParams* P, void* stream, void* start, v
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
+extern "C" int rh_launch_scan_layout(const rh::KParams* P, const rh::LParams* L, void* stream, void* start, void* stop) {
+  hipExtLaunchKernelGGL(rh::rh_k_scan_layout, dim3((uint32_t)P->K * P->k), dim3(rh::kBlock), 0, (hipStream_t)stream, (hipEvent_t)start,
+                        (hipEvent_t)stop, 0, *P, *L);
+  return (int)hipGetLastError();
+}
+
 extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf,
                               uint32_t k, const unsigned long long* ctrl, void* stream) {
   hipLaunchKernelGGL(rh::rh_k_init, dim3(nbuf * k), dim3(rh::kBlock), 0, (hipStream_t)stream, bufptr, bufsize, desc,

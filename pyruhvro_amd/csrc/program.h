@@ -184,9 +184,10 @@ struct KParams {
   void* const* bufptr;       // [k][nbuf]
   uint32_t* nullcount;       // [nnodes][k]
   // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
-  uint16_t* lanecnt;         // [K][nblocks*256] per-record counters, saturated at 0xFFFF
+  uint32_t* lanecnt;         // [nblocks*TILE][ceil(K/2)] per-record counters, 16 bits each (saturated at 0xFFFF), record-major
   uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
+  uint32_t all_careful;      // 1: no size pass classified the tiles (schemas without variable-length output): the emit kernel walks every tile carefully
 };
 
 }  // namespace rh

@@ -109,6 +109,37 @@ struct SCtx {
   }
 };
 
+// Per-record counters handed from the size pass to the emit pass: RECORD-major, two 16-bit counters per dword, so a
+// lane moves its K counters with ceil(K/2) dwords in 16 / 8 / 4-byte pieces (two instructions for the benchmark
+// schema's 12 counters) instead of K two-byte accesses at a [counter][record] layout.
+template <int NDW, int I = 0>
+__device__ __forceinline__ void lanecnt_store(uint32_t* row, const uint32_t (&d)[NDW]) {
+  if constexpr (I + 4 <= NDW) {
+    v4w x; x.x = d[I]; x.y = d[I + 1]; x.z = d[I + 2]; x.w = d[I + 3];
+    *reinterpret_cast<RH_GLOBAL v4wu*>(reinterpret_cast<uintptr_t>(row + I)) = x;
+    lanecnt_store<NDW, I + 4>(row, d);
+  } else if constexpr (I + 2 <= NDW) {
+    *reinterpret_cast<RH_GLOBAL u64u*>(reinterpret_cast<uintptr_t>(row + I)) = ((uint64_t)d[I + 1] << 32) | d[I];
+    lanecnt_store<NDW, I + 2>(row, d);
+  } else if constexpr (I < NDW) {
+    *reinterpret_cast<RH_GLOBAL uint32_t*>(reinterpret_cast<uintptr_t>(row + I)) = d[I];
+  }
+}
+template <int NDW, int I = 0>
+__device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[NDW]) {
+  if constexpr (I + 4 <= NDW) {
+    const v4w x = *reinterpret_cast<const RH_GLOBAL v4wu*>(reinterpret_cast<uintptr_t>(row + I));
+    d[I] = x.x; d[I + 1] = x.y; d[I + 2] = x.z; d[I + 3] = x.w;
+    lanecnt_load<NDW, I + 4>(row, d);
+  } else if constexpr (I + 2 <= NDW) {
+    const uint64_t x = *reinterpret_cast<const RH_GLOBAL u64u*>(reinterpret_cast<uintptr_t>(row + I));
+    d[I] = (uint32_t)x; d[I + 1] = (uint32_t)(x >> 32);
+    lanecnt_load<NDW, I + 2>(row, d);
+  } else if constexpr (I < NDW) {
+    d[I] = *reinterpret_cast<const RH_GLOBAL uint32_t*>(reinterpret_cast<uintptr_t>(row + I));
+  }
+}
+
 // LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4] | bm[NBM][kBmWords]   (host mirror: spec_lds_fixed_words_host)
 __host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm) {
   return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords);
@@ -199,16 +230,20 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   }
   RH_MARK(18);
 
-  // per-record counters -> HBM (2 bytes each, coalesced per counter) so that k_emit can skip its size walk
+  // per-record counters -> HBM (16 bits each, record-major: lanecnt_store) so that k_emit can skip its size walk
   bool sat = false;
+  constexpr int NDW = (S::K + 1) / 2;
+  uint32_t packed[NDW > 0 ? NDW : 1] = {};
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
     const uint32_t cv = c.cnt[k];
     sat |= cv > 0xFFFFu;
-    st_global<uint16_t, false>(P.lanecnt + (size_t)k * ((size_t)P.nblocks * T), tile * T + tid, (uint16_t)(cv > 0xFFFFu ? 0xFFFFu : cv));
+    const uint32_t c16 = cv > 0xFFFFu ? 0xFFFFu : cv;
+    packed[k / 2] |= (k & 1) ? c16 << 16 : c16;
     const uint32_t v = wave_sum(cv);
     if (lane == 0) s.wtot[k * NW + wave] = v;
   });
+  if constexpr (S::K > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const bool anysat = __any(sat);
   if (lane == 0 && (anysat || careful)) atomicOr(&s.misc[2], (anysat ? 1u : 0u) | (careful ? 2u : 0u));
   report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
@@ -249,13 +284,16 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
   // this record's counters as k_size left them (requested with the window, so no extra round trip)
-  const uint32_t tflag = P.tileflag[tile];
+  const uint32_t tflag = P.all_careful ? 2u : P.tileflag[tile];
   const uint32_t rewalk = tflag & 1u;
   const bool careful = (tflag & 2u) != 0;
-  if (S::K > 0) {
+  if constexpr (S::K > 0) {
+    constexpr int NDW = (S::K + 1) / 2;
+    uint32_t packed[NDW];
+    lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
-      c.cnt[k] = (P.lanecnt + (size_t)k * ((size_t)P.nblocks * T))[tile * T + tid];
+      c.cnt[k] = (k & 1) ? packed[k / 2] >> 16 : packed[k / 2] & 0xFFFFu;
     });
   }
   const uint64_t wb16 = wb & ~15ull;
