@@ -44,7 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 KERNEL = 0                      # rh_opts.flags: 0 auto, 1 generic interpreter, 2 schema-specialised
-STATS_EVERY = 2                 # every 2nd timed step carries the kernel timestamps (see run())
+STATS_EVERY = 2                 # every 2nd timed step carries the kernel timestamps (see run(); --stats-every)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOADS = {
     # name: (generator config, records per GPU, num_chunks, description)
@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="full10m", choices=sorted(WORKLOADS))
     ap.add_argument("--records", type=int, default=0, help="override records per GPU (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stats-every", type=int, default=STATS_EVERY,
+                    help="every Nth timed step carries the kernels' HIP-event timestamps (costs such a step ~30 us)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="records of the CPU baseline (0 = the whole workload)")
@@ -216,7 +218,7 @@ def run(args, make_step=None, backend="nccl"):
     acc = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0}
     sampled = 0
     for i in range(args.steps):
-        want = i % STATS_EVERY == 0
+        want = i % max(getattr(args, "stats_every", STATS_EVERY), 1) == 0
         st = step(want) if use_cuda else step()
         if want or not use_cuda:
             sampled += 1
@@ -427,7 +429,7 @@ def main(argv=None):
                 "traffic": traffic[emit_kernel]["hbm_bytes"] if emit_kernel in traffic else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_record": alg_bytes / max(rs["records"], 1), "avg_launch_ms": emit_ms,
-                "timed_launches": (args.steps + STATS_EVERY - 1) // STATS_EVERY,
+                "timed_launches": (args.steps + args.stats_every - 1) // max(args.stats_every, 1),
                 # the whole path (k_size + k_scan + k_emit) against the same algorithmic bytes, and the north star's own
                 # figure: HBM READ bandwidth of the two passes together (rocprofv3 FETCH_SIZE of both / their time)
                 "path_achieved": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,

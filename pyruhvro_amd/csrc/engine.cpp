@@ -208,6 +208,59 @@ struct Lease {   // RAII pool block
   uint8_t* ptr() const { return (uint8_t*)b.p; }
 };
 
+// Control blocks of the decode calls (first_bad, layout flag, ticket, null counts, chunk totals -- program.h): handed
+// out ALL ZERO and zeroed again when they come back -- asynchronously, on the stream of the call that used them.  The
+// next call on that stream is ordered behind that memset, so no call has a memset in front of its first kernel any
+// more (2 us of fill kernel + the gap behind it, at the head of every call: profiles/r03e_timeline_*.txt).
+class CtrlPool {
+ public:
+  struct Blk { void* p = nullptr; uint64_t size = 0; int device = 0; hipStream_t stream = nullptr; };
+  Blk get(uint64_t size, int device, hipStream_t stream) {
+    size = align_up(std::max<uint64_t>(size, 1), 4096);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      for (size_t i = 0; i < free_.size(); i++)
+        if (free_[i].device == device && free_[i].stream == stream && free_[i].size == size) {
+          Blk b = free_[i];
+          free_.erase(free_.begin() + (long)i);
+          return b;
+        }
+    }
+    Blk b;
+    b.size = size; b.device = device; b.stream = stream;
+    hipError_t e = hipMalloc(&b.p, size);
+    if (e != hipSuccess) throw HipError(std::string("HIP allocation of a control block failed: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(b.p, 0, size, stream);          // ordered before the kernels of the call that asked for it
+    if (e != hipSuccess) { (void)hipFree(b.p); throw HipError(std::string("hipMemsetAsync failed: ") + hipGetErrorString(e)); }
+    return b;
+  }
+  void put(Blk b) {
+    if (!b.p) return;
+    if (hipMemsetAsync(b.p, 0, b.size, b.stream) != hipSuccess) { (void)hipFree(b.p); return; }
+    Blk drop;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      free_.push_back(b);
+      if (free_.size() > 64) { drop = free_.front(); free_.erase(free_.begin()); }   // streams that went away
+    }
+    if (drop.p) (void)hipFree(drop.p);
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<Blk> free_;
+};
+CtrlPool& ctrl_pool() { static CtrlPool* p = new CtrlPool(); return *p; }
+
+struct CtrlLease {
+  CtrlPool::Blk b;
+  CtrlLease(uint64_t size, int device, hipStream_t stream) : b(ctrl_pool().get(size, device, stream)) {}
+  CtrlLease(const CtrlLease&) = delete;
+  CtrlLease& operator=(const CtrlLease&) = delete;
+  ~CtrlLease() { ctrl_pool().put(b); }
+  uint8_t* ptr() const { return (uint8_t*)b.p; }
+};
+
 // ---------------------------------------------------------------------------
 // compiled schema + its per-device copy
 // ---------------------------------------------------------------------------
@@ -437,9 +490,43 @@ struct rh_device_result {
   std::vector<uint64_t> data_bytes;    // [K][k] totals
   std::vector<uint32_t> nullcount;     // [nnodes][k]
   uint64_t output_bytes = 0;           // exact (unpadded) Arrow bytes
+  // The [buf][chunk] tables above are a pure function of (schema, chunk geometry, data_bytes).  A call whose arena was
+  // laid out on the device (and accepted) leaves them to the first reader: tables() -- export, host copy, byte counts.
+  std::once_flag tables_once;
+  bool tables_done = false;
 
   uint64_t rows(int dom, uint32_t c) const { return dom_rows[(size_t)dom * k + c]; }
+  void fill_tables();                  // host statement of the layout rule (program.h buf_bytes / buf_slot_bytes)
+  void tables() { std::call_once(tables_once, [this] { if (!tables_done) fill_tables(); }); }
 };
+
+void rh_device_result::fill_tables() {
+  const CompiledSchema& c_s = *cs;
+  const int nbuf = (int)c_s.bufs.size();
+  dom_rows.assign((size_t)c_s.ndom * k, 0);
+  for (uint32_t c = 0; c < k; c++) {
+    dom_rows[c] = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
+    for (int d = 1; d < c_s.ndom; d++) dom_rows[(size_t)d * k + c] = data_bytes[(size_t)(d - 1) * k + c];
+  }
+  buf_off.assign((size_t)nbuf * k, 0);
+  buf_size.assign((size_t)nbuf * k, 0);
+  uint64_t off = 0, exact = 0;
+  for (uint32_t c = 0; c < k; c++) {
+    for (int b = 0; b < nbuf; b++) {
+      const rh::BufDesc& d = c_s.bufs[b];
+      uint64_t ex = 0;
+      const uint64_t bytes = rh::buf_bytes(d.kind, rows(d.dom, c), d.kind == rh::BK_DATA ? data_bytes[(size_t)d.counter * k + c] : 0, &ex,
+                                           (uint32_t)d.counter);
+      buf_off[(size_t)b * k + c] = off;
+      buf_size[(size_t)b * k + c] = bytes;
+      off += rh::buf_slot_bytes(bytes);
+      exact += ex;
+    }
+  }
+  arena_bytes = std::max<uint64_t>(off, 256);
+  output_bytes = exact;
+  tables_done = true;
+}
 
 namespace {
 
@@ -626,8 +713,32 @@ long env_long(const char* name, long dflt, long lo, long hi) {
 struct Events {
   hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool on = false;
-  void init() { for (auto& x : e) HIPCHK(hipEventCreate(&x)); on = true; }
-  ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+  int device = 0;
+  // events are recycled per device: creating and destroying six of them was a third of what a timed call cost
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::map<int, std::vector<hipEvent_t>>& idle() { static auto* v = new std::map<int, std::vector<hipEvent_t>>(); return *v; }
+  void init() {
+    HIPCHK(hipGetDevice(&device));
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto& v = idle()[device];
+      for (auto& x : e)
+        if (!v.empty()) { x = v.back(); v.pop_back(); }
+    }
+    for (auto& x : e)
+      if (!x) HIPCHK(hipEventCreate(&x));
+    on = true;
+  }
+  ~Events() {
+    if (!on) return;
+    std::lock_guard<std::mutex> g(mu());
+    auto& v = idle()[device];
+    for (auto& x : e) {
+      if (!x) continue;
+      if (v.size() < 64) v.push_back(x);
+      else (void)hipEventDestroy(x);
+    }
+  }
   void rec(int i, hipStream_t s) { if (on) HIPCHK(hipEventRecord(e[i], s)); }
   hipEvent_t at(int i) const { return on ? e[i] : nullptr; }
   float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
@@ -728,7 +839,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   const uint64_t o_null = 32;     // control words first (program.h): first_bad, layout flag, arena bytes used
   const uint64_t o_tot = align_up(o_null + 4ull * nnodes * k, 8);
   const uint64_t ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
-  const uint64_t o_err = ctrl_bytes;
+  const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
   const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
   const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
   const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
@@ -737,9 +848,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   hp.mark("setup");
   Lease ws(dev_pool(), ws_bytes, device);
   Lease hctrl(pin_pool(), ctrl_bytes, device);
+  CtrlLease ctrl(ctrl_bytes, device, stream);        // all zero (CtrlPool)
   hp.mark("leases");
-  HIPCHK(hipMemsetAsync(ws.ptr(), 0, ctrl_bytes, stream));
-  hp.mark("memset");
 
   rh::KParams P;
   std::memset(&P, 0, sizeof P);
@@ -748,9 +858,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
   P.prog = dp.prog; P.sym_off = dp.sym_off; P.sym_data = dp.sym_data;
   P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
   P.nbuf = nbuf; P.cnt_databuf = dp.cnt_databuf;
-  P.first_bad = (unsigned long long*)ws.ptr();
-  P.nullcount = (uint32_t*)(ws.ptr() + o_null);
-  P.totals = (uint64_t*)(ws.ptr() + o_tot);
+  P.first_bad = (unsigned long long*)ctrl.ptr();
+  P.nullcount = (uint32_t*)(ctrl.ptr() + o_null);
+  P.totals = (uint64_t*)(ctrl.ptr() + o_tot);
   P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
   P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
   P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
@@ -811,11 +921,6 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 
   // host statement of the layout (same rule, same table order as rh_k_layout): fills the result's tables
   auto layout_host = [&]() {
-    r.dom_rows.assign((size_t)cs.ndom * k, 0);
-    for (uint32_t c = 0; c < k; c++) {
-      r.dom_rows[c] = n == 0 ? 0 : (c == k - 1 ? r.rows_last : r.sz);
-      for (int d = 1; d < cs.ndom; d++) r.dom_rows[(size_t)d * k + c] = totals[(size_t)(d - 1) * k + c];
-    }
     r.data_bytes = totals;
     for (auto t : totals)
       if (t > 0x7FFFFFFFull) {
@@ -826,24 +931,8 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       for (int d = 1; d < cs.ndom; d++)
         for (uint32_t c = 0; c < k; c++)
           if (totals[(size_t)(d - 1) * k + c] >= narrow_rows) throw NeedWideIndex();
-    r.buf_off.assign((size_t)nbuf * k, 0);
-    r.buf_size.assign((size_t)nbuf * k, 0);
-    uint64_t off = 0;
-    exact = 0;
-    for (uint32_t c = 0; c < k; c++) {
-      for (int b = 0; b < nbuf; b++) {
-        const rh::BufDesc& d = cs.bufs[b];
-        uint64_t ex = 0;
-        const uint64_t sz = rh::buf_bytes(d.kind, r.rows(d.dom, c), d.kind == rh::BK_DATA ? totals[(size_t)d.counter * k + c] : 0, &ex,
-                                          (uint32_t)d.counter);
-        r.buf_off[(size_t)b * k + c] = off;
-        r.buf_size[(size_t)b * k + c] = sz;
-        off += rh::buf_slot_bytes(sz);
-        exact += ex;
-      }
-    }
-    r.arena_bytes = std::max<uint64_t>(off, kAlign);
-    r.output_bytes = exact;
+    r.fill_tables();
+    exact = r.output_bytes;
   };
   bool child_bitmaps = false;     // bitmaps of child row domains are built with atomics on zeroed words
   for (const rh::BufDesc& d : cs.bufs) child_bitmaps = child_bitmaps || (d.kind == rh::BK_BITMAP && d.dom != 0);
@@ -872,9 +961,9 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
         hsz[(size_t)c * nbuf + b] = r.buf_size[(size_t)b * k + c];
       }
     HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ws.ptr() + 8, 0, 8, stream));      // clear the layout flag of a refused optimistic attempt
+    HIPCHK(hipMemsetAsync(ctrl.ptr() + 8, 0, 8, stream));    // clear the layout flag (and the ticket) of a refused optimistic attempt
     launch_tail(false);
-    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));      // also keeps htab alive until the table copy is done
     check_bad(hctrl.ptr());
   };
@@ -914,7 +1003,7 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       throw HipError("k_scan / k_layout launch failed");
     launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
     hp.mark("layout+emit_launch");
-    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
     hp.mark("d2h_enqueue");
     HIPCHK(hipStreamSynchronize(stream));
     hp.mark("sync");
@@ -925,15 +1014,20 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       count(RH_CTR_CAPACITY_RETRIES);
       r.arena.release();
       exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
-    } else {
+    } else if (lflag || stats) {
       layout_host();                             // throws for LF_OFFSET32 / LF_NEED_WIDE: same tests on the same totals
       if (lflag) throw HipError("internal error: layout kernel and host disagree");
       if (r.arena_bytes != std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign)) throw HipError("internal error: device and host arena layouts differ");
+    } else {
+      // the device laid the arena out and accepted it: the host's tables (same rule, same totals) wait for their first
+      // reader (rh_device_result::tables) -- a caller that only hands the device buffers on never pays for them
+      r.data_bytes = totals;
+      r.arena_bytes = std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign);
     }
   } else {
     count(RH_CTR_TWO_SYNC_CALLS);
     if (n > 0 && K > 0) {
-      HIPCHK(hipMemcpyAsync(hctrl.ptr(), ws.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
       check_bad(hctrl.ptr());
       std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
@@ -1008,6 +1102,7 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStrea
 }
 
 int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream = nullptr) {
+  r->tables();
   Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
   slab->refs.store(1);   // guard while building
   uint32_t built = 0;
@@ -1637,11 +1732,16 @@ int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
 
 uint32_t rh_device_result_chunks(const rh_device_result* r) { return r ? r->k : 0; }
 
-uint64_t rh_device_result_output_bytes(const rh_device_result* r) { return r ? r->output_bytes : 0; }
+uint64_t rh_device_result_output_bytes(const rh_device_result* r) {
+  if (!r) return 0;
+  const_cast<rh_device_result*>(r)->tables();
+  return r->output_bytes;
+}
 
 int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDeviceArray* out) {
   if (!r || !out || chunk >= r->k) return RH_ERR_ARGUMENT;
   std::memset(out, 0, sizeof *out);
+  r->tables();
   export_chunk(*r, chunk, r->arena.ptr(), nullptr, &out->array);
   out->device_id = r->device;
   out->device_type = ARROW_DEVICE_ROCM;

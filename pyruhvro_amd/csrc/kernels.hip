@@ -206,7 +206,13 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P);
 // fence + ticket by the writer, acquire fence by the last workgroup (agent scope; the L2s hold next to nothing dirty
 // here, so the fences are cheap -- unlike in a tile look-back).
 // --------------------------------------------------------------------------
-__device__ __forceinline__ void scan_segment(const KParams& P, uint32_t* wt) {
+// kScanPer consecutive tiles per thread and round (serial prefix inside the thread, DPP scan of the thread sums across
+// the wave, four wave totals through LDS).  Long segments take 8 per thread: a 4883-tile chunk (1.25M records, what
+// ONE rank of the 8-GPU configuration scans in a single workgroup per counter) is 3 rounds of two barriers instead of
+// 20 (rh_k_scan_layout 17 -> 9 us there, 22 -> 19 us at 10M records / 8 chunks); short ones keep one tile per thread
+// (a 489-tile segment of a 1M-record call was 2 us slower with 8).
+template <uint32_t kScanPer>
+__device__ __forceinline__ void scan_segment_n(const KParams& P, uint32_t* wt) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t kk = blockIdx.x % (uint32_t)P.K, ch = blockIdx.x / (uint32_t)P.K;
   const uint32_t b0 = ch * P.bpc;
@@ -214,20 +220,36 @@ __device__ __forceinline__ void scan_segment(const KParams& P, uint32_t* wt) {
   const uint32_t* in = P.blocksum + (size_t)kk * P.nblocks;
   uint32_t* out = P.blockbase + (size_t)kk * P.nblocks;
   uint64_t carry = 0;
-  for (uint32_t base = b0; base < b1; base += kBlock) {
-    const uint32_t i = base + tid;
-    const uint32_t v = i < b1 ? in[i] : 0;
-    const uint32_t incl = wave_incl_scan(v, lane);
+  for (uint32_t base = b0; base < b1; base += kBlock * kScanPer) {
+    const uint32_t i0 = base + tid * kScanPer;
+    uint32_t v[kScanPer];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer; j++) {
+      v[j] = i0 + j < b1 ? in[i0 + j] : 0;
+      sum += v[j];
+    }
+    const uint32_t incl = wave_incl_scan(sum, lane);
     if (lane == 63) wt[wave] = incl;
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t w = 0; w < wave; w++) woff += wt[w];
-    const uint32_t tile = wt[0] + wt[1] + wt[2] + wt[3];
-    if (i < b1) out[i] = (uint32_t)(carry + woff + (incl - v));
-    carry += tile;
+    const uint32_t round = wt[0] + wt[1] + wt[2] + wt[3];
+    uint32_t run = (uint32_t)(carry + woff + (incl - sum));
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer; j++) {
+      if (i0 + j < b1) out[i0 + j] = run;
+      run += v[j];
+    }
+    carry += round;
     __syncthreads();
   }
   if (tid == 0) P.totals[(size_t)kk * P.k + ch] = carry;
+}
+
+__device__ __forceinline__ void scan_segment(const KParams& P, uint32_t* wt) {
+  if (P.bpc > 1024u) scan_segment_n<8>(P, wt);       // (uniform for the launch)
+  else scan_segment_n<1>(P, wt);
 }
 
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan(KParams P) {

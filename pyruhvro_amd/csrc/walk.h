@@ -199,15 +199,12 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
     if (len > 8) st_at<u64u, WIDE>(base, d + len - 8, x1);
   } else {
     const uint64_t x = s.ld8(sp);   // len <= 7: bytes beyond the string are read (inside the window) but not written
-    if (len >= 4) {
-      st_at<u32u, WIDE>(base, d, (uint32_t)x);
-      if (len > 4) st_at<u32u, WIDE>(base, d + len - 4, (uint32_t)(x >> (8 * (len - 4))));
-    } else if (len >= 2) {
-      st_at<u16u, WIDE>(base, d, (uint16_t)x);
-      if (len > 2) st_at<uint8_t, WIDE>(base, d + 2, (uint8_t)(x >> 16));
-    } else {
-      st_at<uint8_t, WIDE>(base, d, (uint8_t)x);
-    }
+    // one store per set bit of the length (4, 2, 1 bytes): at most three instructions for a wave whose short strings
+    // have every length 1..7 (the length classes 4..7 / 2..3 / 1 with overlapping tails took up to five;
+    // k_emit -0.3..-1.8 % in two A/B pairs, profiles/r03g_variants_ab.txt)
+    if (len & 4u) st_at<u32u, WIDE>(base, d, (uint32_t)x);
+    if (len & 2u) st_at<u16u, WIDE>(base, d + (len & 4u), (uint16_t)(x >> (8 * (len & 4u))));
+    if (len & 1u) st_at<uint8_t, WIDE>(base, d + (len & 6u), (uint8_t)(x >> (8 * (len & 6u))));
   }
 }
 

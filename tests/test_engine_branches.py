@@ -41,12 +41,12 @@ def test_arena_capacity_retry(mode, monkeypatch):
     LF_CAPACITY, init / emit return at once and the host re-runs the tail with an exact arena."""
     old = P.set_kernel_mode(mode)
     try:
-        recs = synth.records("full", 6000, seed=5)
+        recs = synth.records("full", 40000, seed=5)             # ~7 MB of Arrow buffers: beyond the reservation's fixed 1 MiB slack
         _check(recs, SCHEMAS["full"], 3)                        # gives the schema a history (first call: two submissions)
         monkeypatch.setenv("RUHVRO_HIP_ARENA_PERMILLE", "1")   # "history": 0.001 output bytes per input byte
         c0 = cabi.engine_counters()
         _check(recs, SCHEMAS["full"], 3)
-        _check(synth.records("array_and_map", 3000, seed=1), SCHEMAS["array_and_map"], 4)
+        _check(synth.records("array_and_map", 40000, seed=1), SCHEMAS["array_and_map"], 4)
         d = _delta(c0)
         assert d["capacity_retries"] == 2 and d["fused_calls"] == 2, d
         monkeypatch.delenv("RUHVRO_HIP_ARENA_PERMILLE")
