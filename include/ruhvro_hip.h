@@ -167,6 +167,21 @@ int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct A
               uint64_t num_chunks, const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k,
               rh_stats* stats, char** err);
 
+/* Device-resident form of rh_encode (the mirror of rh_decode_device): `batch` is a struct array whose BUFFER POINTERS
+ * ARE DEVICE POINTERS on the call's device (what rh_device_result_export hands out: ArrowDeviceArray.array), read in
+ * place -- no host copy.  Every buffer must be followed by at least 64 readable bytes (Arrow's own allocation padding;
+ * the arenas of rh_decode_device are).  The k BinaryArrays ("z": i32 offsets + data, chunked like serialize.rs:19-30)
+ * are produced in HBM and stay there: export chunk i as an ArrowDeviceArray (ARROW_DEVICE_ROCM), or copy all to the
+ * host in the form rh_encode returns.  This is the kernel-only path `bench.py --direction encode` times. */
+typedef struct rh_device_encoded rh_device_encoded;
+int rh_encode_device(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema,
+                     uint64_t num_chunks, const rh_opts* opts, rh_device_encoded** out, rh_stats* stats, char** err);
+uint32_t rh_device_encoded_chunks(const rh_device_encoded* r);
+uint64_t rh_device_encoded_output_bytes(const rh_device_encoded* r);   /* exact: i32 offsets + Avro bytes, all chunks */
+int rh_device_encoded_export(rh_device_encoded* r, uint32_t chunk, struct ArrowDeviceArray* out);
+int rh_device_encoded_to_host(rh_device_encoded* r, struct ArrowArray* out_chunks, char** err);
+void rh_device_encoded_free(rh_device_encoded* r);
+
 /* Process-wide counters of the engine's rarely taken branches (monotonic; tests read them before and after a call to
  * prove that the branch they aim at really ran).  Fills out[0..n) with as many of the RH_CTR_* values as fit; returns
  * RH_CTR_COUNT. */

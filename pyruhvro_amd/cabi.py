@@ -118,6 +118,15 @@ def lib():
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_device_count.restype = C.c_int
+        L.rh_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(RhOpts), C.POINTER(C.c_void_p),
+                                       C.POINTER(RhStats), C.POINTER(C.c_char_p)]
+        L.rh_device_encoded_chunks.restype = C.c_uint32
+        L.rh_device_encoded_chunks.argtypes = [C.c_void_p]
+        L.rh_device_encoded_output_bytes.restype = C.c_uint64
+        L.rh_device_encoded_output_bytes.argtypes = [C.c_void_p]
+        L.rh_device_encoded_export.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ArrowDeviceArray)]
+        L.rh_device_encoded_to_host.argtypes = [C.c_void_p, C.POINTER(ArrowArray), C.POINTER(C.c_char_p)]
+        L.rh_device_encoded_free.argtypes = [C.c_void_p]
         L.rh_engine_counters.restype = C.c_uint32
         L.rh_engine_counters.argtypes = [C.POINTER(C.c_uint64), C.c_uint32]
         _lib = L
@@ -305,6 +314,13 @@ class DeviceResult:
     def output_bytes(self) -> int:
         return lib().rh_device_result_output_bytes(self.handle)
 
+    def export(self, chunk: int) -> "ArrowDeviceArray":
+        """Chunk `chunk` as an ArrowDeviceArray view (device pointers); release it through array.release."""
+        out = ArrowDeviceArray()
+        if lib().rh_device_result_export(self.handle, chunk, C.byref(out)) != RH_OK:
+            raise RuntimeError("rh_device_result_export failed")
+        return out
+
     def to_host(self) -> List[pa.RecordBatch]:
         k = self.chunks
         arr = (ArrowArray * k)()
@@ -324,6 +340,73 @@ class DeviceResult:
             self.free()
         except Exception:
             pass
+
+
+class DeviceEncoded:
+    """Owns an rh_device_encoded (k BinaryArrays of Avro datums resident in HBM)."""
+
+    def __init__(self, handle, stats: dict):
+        self.handle = handle
+        self.stats = stats
+
+    @property
+    def chunks(self) -> int:
+        return lib().rh_device_encoded_chunks(self.handle)
+
+    @property
+    def output_bytes(self) -> int:
+        return lib().rh_device_encoded_output_bytes(self.handle)
+
+    def export(self, chunk: int) -> "ArrowDeviceArray":
+        out = ArrowDeviceArray()
+        if lib().rh_device_encoded_export(self.handle, chunk, C.byref(out)) != RH_OK:
+            raise RuntimeError("rh_device_encoded_export failed")
+        return out
+
+    def to_host(self) -> List[pa.Array]:
+        k = self.chunks
+        arr = (ArrowArray * k)()
+        err = C.c_char_p()
+        rc = lib().rh_device_encoded_to_host(self.handle, arr, C.byref(err))
+        if rc != RH_OK:
+            _raise(rc, err)
+        return [pa.Array._import_from_c(C.addressof(arr[i]), pa.binary()) for i in range(k)]
+
+    def free(self):
+        if self.handle:
+            lib().rh_device_encoded_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def schema_struct(schema_json: str) -> "ArrowSchema":
+    """The schema's batches as an Arrow C ArrowSchema ("+s" struct; the caller releases it)."""
+    cs = ArrowSchema()
+    if lib().rh_schema_export(Schema.get(schema_json).handle, C.byref(cs)) != RH_OK:
+        raise RuntimeError("rh_schema_export failed")
+    return cs
+
+
+def encode_device(batch_array_addr: int, batch_schema_addr: int, schema_json: str, num_chunks: int, device: int = -1,
+                  stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO) -> DeviceEncoded:
+    """rh_encode_device: `batch_array_addr` is the address of a struct ArrowArray whose buffer pointers are DEVICE
+    pointers (e.g. ctypes.addressof(device_result_export.array)); `batch_schema_addr` of its ArrowSchema."""
+    L = lib()
+    s = Schema.get(schema_json)
+    out = C.c_void_p()
+    st = RhStats()
+    err = C.c_char_p()
+    opts, _keep = make_opts(device, kernel, stream, None, 0)
+    rc = L.rh_encode_device(s.handle, batch_array_addr, batch_schema_addr, num_chunks, C.byref(opts), C.byref(out),
+                            C.byref(st) if want_stats else None, C.byref(err))
+    if rc != RH_OK:
+        _raise(rc, err)
+    return DeviceEncoded(out.value, st.as_dict())
 
 
 def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,

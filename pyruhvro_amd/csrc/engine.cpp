@@ -528,6 +528,18 @@ void rh_device_result::fill_tables() {
   tables_done = true;
 }
 
+struct rh_device_encoded {             // result of rh_encode_device: k BinaryArrays in HBM
+  int device = 0;
+  uint64_t n = 0, sz = 0, rows_last = 0;
+  uint32_t k = 1;
+  Lease out;                           // per chunk: i32 offsets[rows + 1] | data
+  uint64_t out_bytes = 0;              // bytes of `out` in use
+  std::vector<uint64_t> ooff;          // [k][2] offsets of the two buffers
+  std::vector<uint64_t> data_bytes;    // [k] Avro bytes per chunk
+  uint64_t exact = 0;
+  uint64_t rows(uint32_t c) const { return n == 0 ? 0 : (c == k - 1 ? rows_last : sz); }
+};
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -1804,6 +1816,7 @@ struct StrSrc {           // where a string / enum node's text lives on the host
 // Arrow C Data structs in lockstep, matching record fields to struct children BY NAME.
 struct EncodeBinder {
   const CompiledSchema& cs;
+  bool device_ptrs = false;   // rh_encode_device: the batch's buffer pointers are device pointers (never dereferenced here)
   std::vector<InBuf> in;
   std::vector<StrSrc> strs;   // by node id
   uint64_t max_rows = 0;      // longest array bound (sizes the shared all-ones validity bitmap)
@@ -1876,7 +1889,8 @@ struct EncodeBinder {
           const int32_t* offs = (const int32_t*)fa->buffers[1] + off;
           in[n.buf_main].host = (const uint8_t*)offs;
           in[n.buf_main].bytes = (uint64_t)(len + 1) * 4;
-          const uint64_t dbytes = fa->buffers[2] ? (uint64_t)offs[len] : 0;
+          // (device pointers: the data length lives in HBM and is not needed -- nothing is copied)
+          const uint64_t dbytes = fa->buffers[2] ? (device_ptrs ? 1 : (uint64_t)offs[len]) : 0;
           in[n.buf_data].host = dbytes ? (const uint8_t*)fa->buffers[2] : nullptr;
           in[n.buf_data].bytes = dbytes;
           strs[id].offsets = offs;
@@ -1963,7 +1977,7 @@ struct BinPriv {          // one produced BinaryArray; the k chunks share one ho
 void release_binary(ArrowArray* a) {
   if (!a || !a->release) return;
   BinPriv* p = (BinPriv*)a->private_data;
-  if (p->slab->refs.fetch_sub(1) == 1) {
+  if (p->slab && p->slab->refs.fetch_sub(1) == 1) {
     p->slab->free_mem();
     delete p->slab;
   }
@@ -1981,15 +1995,45 @@ std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, 
     const int node = cs.prog[e.pad].node;
     const StrSrc& s = b.strs[node];
     std::string sym;
-    if (s.offsets && s.data) sym.assign((const char*)s.data + s.offsets[e.detail], (size_t)(s.offsets[e.detail + 1] - s.offsets[e.detail]));
+    if (s.offsets && s.data && b.device_ptrs) {
+      int32_t o[2] = {0, 0};
+      if (hipMemcpy(o, s.offsets + e.detail, sizeof o, hipMemcpyDeviceToHost) == hipSuccess && o[1] > o[0] && o[1] - o[0] < (1 << 20)) {
+        sym.resize((size_t)(o[1] - o[0]));
+        if (hipMemcpy(&sym[0], s.data + o[0], sym.size(), hipMemcpyDeviceToHost) != hipSuccess) sym.clear();
+      }
+    } else if (s.offsets && s.data) {
+      sym.assign((const char*)s.data + s.offsets[e.detail], (size_t)(s.offsets[e.detail + 1] - s.offsets[e.detail]));
+    }
     return "fast_encode: enum symbol '" + sym + "' not in schema";
   }
   std::snprintf(buf, sizeof buf, "encode error (code %u, op %u, detail %lld)", e.code, e.pad, (long long)e.detail);
   return buf;
 }
 
+// k BinaryArrays over one host slab holding a copy of the device output (what rh_encode returns)
+void binary_chunks_to_host(const uint8_t* d_out, uint64_t out_bytes, int device, uint64_t n, uint64_t sz, uint64_t rows_last, uint32_t k,
+                           const std::vector<uint64_t>& ooff, ArrowArray* out_chunks) {
+  Slab* slab = slab_from_device(d_out, std::max<uint64_t>(out_bytes, 4), device);
+  slab->refs.store((int)k);
+  for (uint32_t c = 0; c < k; c++) {
+    const uint64_t rows = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
+    BinPriv* p = new BinPriv();
+    p->slab = slab;
+    p->buffers[0] = nullptr;
+    p->buffers[1] = (const uint8_t*)slab->base + ooff[(size_t)c * 2];
+    p->buffers[2] = (const uint8_t*)slab->base + ooff[(size_t)c * 2 + 1];
+    ArrowArray* a = &out_chunks[c];
+    a->length = (int64_t)rows; a->null_count = 0; a->offset = 0;
+    a->n_buffers = 3; a->n_children = 0; a->buffers = p->buffers; a->children = nullptr; a->dictionary = nullptr;
+    a->release = release_binary; a->private_data = p;
+  }
+}
+
+// `dev_out` != nullptr: rh_encode_device -- the batch's buffers are device pointers, read in place, and the BinaryArrays
+// stay in HBM (*dev_out owns them); else rh_encode -- host batch in, host BinaryArrays out.
 int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschema, uint64_t num_chunks, const rh_opts* opts,
-                ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats) {
+                ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, rh_device_encoded** dev_out = nullptr) {
+  const bool dev = dev_out != nullptr;
   const CompiledSchema& cs = *s->cs;
   if (!cs.encode_unsupported.empty())
     throw rh::SchemaError("schema is outside the GPU encode path (" + cs.encode_unsupported +
@@ -1998,6 +2042,7 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   // schema / batch mismatches are reported before any device work, like the encoder construction of
   // fast_encode.rs:33-37 that runs before the first row is written
   EncodeBinder binder(cs);
+  binder.device_ptrs = dev;
   const uint64_t n = (uint64_t)batch->length;
   binder.bind(*cs.avro, 0, bschema, batch, batch->offset, (int64_t)n);
 
@@ -2020,23 +2065,30 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   // ---- inputs -> HBM.  Every buffer is rebased to logical row 0 and padded so that the kernels' unconditional
   // loads (encode_walk.h: row cursors up to one past the last row, 32-byte string reads) stay inside the arena; a validity bitmap the batch does
   // not carry (no nulls) is the shared all-ones bitmap at the end.
+  // Device-resident input (rh_encode_device) is read where it lies; only the all-ones bitmap and one zero page for
+  // absent / empty buffers are allocated.
   std::vector<uint64_t> ioff((size_t)nbuf, 0);
   uint64_t itot = 0;
   for (int b = 0; b < nbuf; b++) {
     ioff[b] = itot;
-    itot += align_up(binder.in[b].bytes + 64, kAlign);
+    if (!dev) itot += align_up(binder.in[b].bytes + 64, kAlign);
   }
+  if (dev) itot = kAlign;                      // the zero page every absent buffer points at
   const uint64_t o_ones = itot;
   const uint64_t ones_bytes = align_up(binder.max_rows / 8 + 16, kAlign);
   itot += ones_bytes;
   Lease din(dev_pool(), itot, device);
   Timer th;
   HIPCHK(hipMemsetAsync(din.ptr() + o_ones, 0xFF, ones_bytes, stream));
-  for (int b = 0; b < nbuf; b++) {
-    if (binder.in[b].host && binder.in[b].bytes)
-      HIPCHK(hipMemcpyAsync(din.ptr() + ioff[b], binder.in[b].host, binder.in[b].bytes, hipMemcpyHostToDevice, stream));
-    else     // an empty column: zero offsets keep the kernels' unconditional second-level loads inside the arena
-      HIPCHK(hipMemsetAsync(din.ptr() + ioff[b], 0, kAlign, stream));
+  if (dev) {
+    HIPCHK(hipMemsetAsync(din.ptr(), 0, kAlign, stream));
+  } else {
+    for (int b = 0; b < nbuf; b++) {
+      if (binder.in[b].host && binder.in[b].bytes)
+        HIPCHK(hipMemcpyAsync(din.ptr() + ioff[b], binder.in[b].host, binder.in[b].bytes, hipMemcpyHostToDevice, stream));
+      else     // an empty column: zero offsets keep the kernels' unconditional second-level loads inside the arena
+        HIPCHK(hipMemsetAsync(din.ptr() + ioff[b], 0, kAlign, stream));
+    }
   }
 
   // ---- workspace: [first_bad][totals u64 k] | errinfo | blocksum | blockbase | in_ptr | in_bitoff | outptr
@@ -2060,7 +2112,8 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   for (int b = 0; b < nbuf; b++) {
     const bool have = binder.in[b].host && binder.in[b].bytes;
     const bool bitmap = cs.bufs[b].kind == rh::BK_BITMAP;
-    h_inptr[b] = (uint64_t)(uintptr_t)(din.ptr() + (have || !bitmap ? ioff[b] : o_ones));
+    if (dev) h_inptr[b] = have ? (uint64_t)(uintptr_t)binder.in[b].host : (uint64_t)(uintptr_t)(din.ptr() + (bitmap ? o_ones : 0));
+    else h_inptr[b] = (uint64_t)(uintptr_t)(din.ptr() + (have || !bitmap ? ioff[b] : o_ones));
     h_bitoff[b] = have ? binder.in[b].bitoff : 0;
   }
 
@@ -2196,28 +2249,26 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
     std::fprintf(stderr, " | walk_tail=%.0f barrier=%.0f stream_out=%.0f\n", h[20] / waves, h[21] / waves, h[22] / waves);
   }
 
-  // ---- results -> host, one slab shared by the k BinaryArrays
+  // ---- results: left in HBM (rh_encode_device) or -> host, one slab shared by the k BinaryArrays
   Timer td;
-  Slab* slab = slab_from_device(dout.ptr(), std::max<uint64_t>(otot, 4), device);
-  slab->refs.store((int)k);
-  for (uint32_t c = 0; c < k; c++) {
-    const uint64_t rows = n == 0 ? 0 : (c == k - 1 ? rows_last : sz);
-    BinPriv* p = new BinPriv();
-    p->slab = slab;
-    p->buffers[0] = nullptr;
-    p->buffers[1] = (const uint8_t*)slab->base + ooff[(size_t)c * 2];
-    p->buffers[2] = (const uint8_t*)slab->base + ooff[(size_t)c * 2 + 1];
-    ArrowArray* a = &out_chunks[c];
-    a->length = (int64_t)rows; a->null_count = 0; a->offset = 0;
-    a->n_buffers = 3; a->n_children = 0; a->buffers = p->buffers; a->children = nullptr; a->dictionary = nullptr;
-    a->release = release_binary; a->private_data = p;
+  if (dev) {
+    auto res = std::make_unique<rh_device_encoded>();
+    res->device = device; res->n = n; res->sz = sz; res->rows_last = rows_last; res->k = k;
+    res->out = std::move(dout);
+    res->out_bytes = std::max<uint64_t>(otot, 4);
+    res->ooff = ooff;
+    res->data_bytes = totals;
+    res->exact = exact;
+    *dev_out = res.release();
+  } else {
+    binary_chunks_to_host(dout.ptr(), otot, device, n, sz, rows_last, k, ooff, out_chunks);
   }
   if (out_k) *out_k = k;
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     stats->records = n;
     stats->output_bytes = exact;
-    for (int b = 0; b < nbuf; b++) stats->input_bytes += binder.in[b].bytes;
+    for (int b = 0; b < nbuf; b++) stats->input_bytes += binder.in[b].bytes;   // (device input: string data bytes are not known here)
     stats->chunks = k;
     stats->blocks = nblocks;
     stats->h2d_ms = h2d;
@@ -2233,6 +2284,42 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
 }
 
 }  // namespace
+
+extern "C" int rh_encode_device(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema, uint64_t num_chunks,
+                                const rh_opts* opts, rh_device_encoded** out, rh_stats* stats, char** err) {
+  if (!s || !batch || !batch_schema || !out) return RH_ERR_ARGUMENT;
+  *out = nullptr;
+  return guarded(err, [&] { return encode_impl(const_cast<rh_schema*>(s), batch, batch_schema, num_chunks, opts, nullptr, nullptr, stats, out); });
+}
+extern "C" uint32_t rh_device_encoded_chunks(const rh_device_encoded* r) { return r ? r->k : 0; }
+extern "C" uint64_t rh_device_encoded_output_bytes(const rh_device_encoded* r) { return r ? r->exact : 0; }
+extern "C" int rh_device_encoded_export(rh_device_encoded* r, uint32_t chunk, struct ArrowDeviceArray* out) {
+  if (!r || !out || chunk >= r->k) return RH_ERR_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  BinPriv* p = new BinPriv();
+  p->slab = nullptr;                     // a view: the memory belongs to the rh_device_encoded
+  p->buffers[0] = nullptr;
+  p->buffers[1] = r->out.ptr() + r->ooff[(size_t)chunk * 2];
+  p->buffers[2] = r->out.ptr() + r->ooff[(size_t)chunk * 2 + 1];
+  ArrowArray* a = &out->array;
+  a->length = (int64_t)r->rows(chunk); a->null_count = 0; a->offset = 0;
+  a->n_buffers = 3; a->n_children = 0; a->buffers = p->buffers; a->children = nullptr; a->dictionary = nullptr;
+  a->release = release_binary; a->private_data = p;
+  out->device_id = r->device;
+  out->device_type = ARROW_DEVICE_ROCM;
+  out->sync_event = nullptr;             // the producing stream was synchronised before the result was returned
+  return RH_OK;
+}
+extern "C" int rh_device_encoded_to_host(rh_device_encoded* r, struct ArrowArray* out_chunks, char** err) {
+  if (!r || !out_chunks) return RH_ERR_ARGUMENT;
+  std::memset(out_chunks, 0, sizeof(ArrowArray) * r->k);
+  return guarded(err, [&] {
+    HIPCHK(hipSetDevice(r->device));
+    binary_chunks_to_host(r->out.ptr(), r->out_bytes, r->device, r->n, r->sz, r->rows_last, r->k, r->ooff, out_chunks);
+    return (int)RH_OK;
+  });
+}
+extern "C" void rh_device_encoded_free(rh_device_encoded* r) { delete r; }
 
 extern "C" int rh_encode(const rh_schema* s, const struct ArrowArray* batch, const struct ArrowSchema* batch_schema, uint64_t num_chunks,
                          const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {

@@ -273,3 +273,79 @@ def test_enum_symbols_short_and_longer_than_sixteen_bytes():
         with pytest.raises(ValueError) as ei:
             P.serialize_record_batch(pa.RecordBatch.from_arrays([pa.array(e2), pa.array(f2)], names=["e", "f"]), s, 1)
         assert str(ei.value) == "fast_encode: enum symbol '%s' not in schema" % msg
+
+
+# ---- device-resident form (rh_encode_device): Arrow buffers in HBM -> "z" arrays in HBM ---------------------------
+
+def _device_batch(name, n, seed=3):
+    """Records decoded on the GPU with the result left in HBM: (DeviceResult, records, schema json)."""
+    import hipmem
+    recs = synth.records(name, n, seed=seed)
+    data, offsets = c_walker.pack(recs)
+    d_data, d_off = hipmem.upload_packed(data, offsets)
+    r = cabi.decode_device(d_data.ptr, d_off.ptr, int(offsets[-1]), len(recs), SCHEMAS[name], 1, device=0)
+    return r, recs, SCHEMAS[name]
+
+
+@pytest.mark.parametrize("name,n,k", [("full", 5003, 7), ("cfg3", 3000, 2), ("array_and_map", 2500, 3), ("full", 1, 1),
+                                      ("nullable_primitives", 4000, 5), ("flat4", 777, 1)])
+def test_device_resident_encode(name, n, k, kernel):
+    """GPU decode (result stays in HBM) -> rh_encode_device reads those buffers in place -> BinaryArrays in HBM: the
+    datums equal the records that went in (the generator writes canonical Avro), the oracle encoder's output for the
+    same batch, and the host entry point's; the device export is walked buffer by buffer."""
+    import ctypes as C
+    import hipmem
+    r, recs, schema = _device_batch(name, n)
+    view = r.export(0)                                       # ArrowDeviceArray: device pointers
+    sch = cabi.schema_struct(schema)
+    enc = cabi.encode_device(C.addressof(view.array), C.addressof(sch), schema, k, device=0, kernel=kernel)
+    assert enc.stats["records"] == n and enc.stats["emit_kernel_ms"] > 0 and enc.stats["h2d_ms"] >= 0
+    got = enc.to_host()
+    batch = r.to_host()[0]
+    exp = py_encoder.serialize_record_batch(batch, schema, k)
+    _same(got, exp)
+    assert _datums(got) == recs
+    _same(P.serialize_record_batch(batch, schema, k), exp)
+    assert enc.chunks == len(exp)
+    assert enc.output_bytes == sum(4 * (len(a) + 1) + len(b"".join(a.to_pylist())) for a in exp)
+    # the Arrow C Device view of every chunk: i32 offsets + data, both in HBM
+    for c, e in enumerate(exp):
+        d = enc.export(c)
+        assert d.device_type == 10 and d.array.length == len(e) and d.array.n_buffers == 3 and d.array.null_count == 0
+        offs = hipmem.d2h(d.array.buffers[1], 4 * (len(e) + 1)).view(np.int32)
+        eo = np.frombuffer(e.buffers()[1], dtype=np.int32, count=e.offset + len(e) + 1)[e.offset:]
+        assert np.array_equal(offs, eo - eo[0])
+        if offs[-1]:
+            assert hipmem.d2h(d.array.buffers[2], int(offs[-1])).tobytes() == b"".join(e.to_pylist())
+        C.CFUNCTYPE(None, C.POINTER(cabi.ArrowArray))(d.array.release)(C.byref(d.array))
+    C.CFUNCTYPE(None, C.POINTER(cabi.ArrowArray))(view.array.release)(C.byref(view.array))
+    enc.free()
+    r.free()
+
+
+def test_device_resident_encode_errors(kernel):
+    """Data-dependent failures of the device-resident form carry the reference's text too (the enum symbol is fetched
+    from HBM for the message, fast_encode.rs:576)."""
+    import ctypes as C
+    import hipmem
+    schema = json.dumps({"type": "record", "name": "E", "fields": [{"name": "e", "type": {"type": "enum", "name": "Suit", "symbols": ["hearts", "clubs"]}}]})
+    # a device batch with a symbol the schema does not have: build the Arrow buffers by hand in HBM
+    syms = [b"hearts", b"spades", b"clubs"]
+    offs = np.zeros(len(syms) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(x) for x in syms])
+    d_offs = hipmem.DevBuf(256).upload(offs)
+    d_data = hipmem.DevBuf(256).upload(np.frombuffer(b"".join(syms), dtype=np.uint8))
+    child_bufs = (C.c_void_p * 3)(None, d_offs.ptr, d_data.ptr)
+    child = cabi.ArrowArray()
+    child.length = 3; child.null_count = 0; child.offset = 0; child.n_buffers = 3; child.n_children = 0
+    child.buffers = C.cast(child_bufs, C.POINTER(C.c_void_p))
+    top_bufs = (C.c_void_p * 1)(None)
+    kids = (C.POINTER(cabi.ArrowArray) * 1)(C.pointer(child))
+    top = cabi.ArrowArray()
+    top.length = 3; top.null_count = 0; top.offset = 0; top.n_buffers = 1; top.n_children = 1
+    top.buffers = C.cast(top_bufs, C.POINTER(C.c_void_p))
+    top.children = C.cast(kids, C.POINTER(C.POINTER(cabi.ArrowArray)))
+    sch = cabi.schema_struct(schema)
+    with pytest.raises(ValueError) as ei:
+        cabi.encode_device(C.addressof(top), C.addressof(sch), schema, 1, device=0, kernel=kernel)
+    assert str(ei.value) == "fast_encode: enum symbol 'spades' not in schema"
