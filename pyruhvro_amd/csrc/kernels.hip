@@ -35,6 +35,7 @@ namespace rh {
 // --------------------------------------------------------------------------
 struct ICtx {
   static constexpr bool kWide = true;   // 64-bit buffer indexing: any chunk size
+  static constexpr bool kSkip = false;
   uint32_t* cnt;             // LDS [K][256]
   uint32_t* rem;             // LDS [depth][256]
   uint32_t* nullcnt;         // LDS [nnodes]

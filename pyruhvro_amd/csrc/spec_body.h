@@ -56,11 +56,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 
 constexpr int kBmWords = 64;      // LDS words per child-domain bitmap and tile (2048 rows before the global fallback)
+constexpr int kDenseCap = 128;    // item positions per wavefront and round of the item-dense list handling (dense_list)
 
 template <class S>
 struct SCtx {
   static constexpr int K1 = S::K > 0 ? S::K : 1;
   static constexpr bool kWide = false;   // 32-bit byte offsets into each buffer (host guards: buffers < 4 GiB per chunk)
+  static constexpr bool kSkip = false;
+  static constexpr bool kDense = S::NDENSE > 0;
+  uint32_t* dtab;                                     // LDS [kDenseCap]: this wavefront's item-position table (dense_list)
+  const uint32_t* wtot_w;                             // LDS: wtot[k * NW + this wave] = this wavefront's total of counter k
   mutable uint32_t cnt[K1];                           // per-lane counters (registers)
   mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
   // this chunk's row of the buffer-address table.  Read-only for the whole launch, so it is addressed through the
@@ -140,9 +145,11 @@ __device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[
   }
 }
 
-// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4] | bm[NBM][kBmWords]   (host mirror: spec_lds_fixed_words_host)
-__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm) {
-  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords);
+// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
+// a dense list)   (host mirror: spec_lds_fixed_words_host)
+__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense) {
+  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
+         (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u);
 }
 
 // Tile geometry of a specialised kernel: S::TILE records = S::TILE threads = NW wavefronts per workgroup.
@@ -159,6 +166,7 @@ struct SpecSmem {
   uint32_t* nullcnt;
   uint32_t* misc;
   uint32_t* bm;
+  uint32_t* dtab;
   uint8_t* win;
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
@@ -166,9 +174,97 @@ struct SpecSmem {
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
     misc = p; p += 4;
     bm = p; p += S::NBM * kBmWords;                   // a multiple of 16 bytes
+    dtab = p; p += S::NDENSE > 0 ? (S::TILE / 64) * kDenseCap : 0;
     win = reinterpret_cast<uint8_t*>(p);
   }
 };
+
+// --------------------------------------------------------------------------
+// Item-dense handling of a top-level array / map without nested lists, in the emit kernel's trusted fast walk.
+//
+// One lane = one record leaves the block loop of a list running for as many iterations as the LONGEST list of the wave,
+// with every store of an iteration (item offsets, string bytes) paying for 64 lanes whatever the number that still has an
+// item (tools/storecost.hip) -- at 0..3 items per record half of the lanes of an average iteration are idle.  Here the
+// record lanes only FIND the items (phase A: block headers + a counters-only skip of the item body, the window position
+// of every item goes to a per-wave LDS table in row order), and the items are then materialised one lane = one ITEM
+// (phase B: 64 consecutive rows of the child domain per step, every lane busy, every store of the step covering one dense
+// span of its column).  An item's byte offsets inside the string columns of the body are the wave scan of the items'
+// sizes (a second counters-only walk of the body, now one lane per item) on top of the wave's base.  The table holds
+// kDenseCap items; a wave with more alternates the two phases in rounds.  Only for tiles the size pass cleared (no
+// anomaly anywhere: RH_TRUST), so neither phase carries an error path; every other tile takes the per-record loop.
+// --------------------------------------------------------------------------
+// LID: index of the list among the schema's dense lists; D: counter of its child row domain; DEPTH: its nesting depth (0).
+template <class S, int LID, int D, int DEPTH, class Src, class Body>
+__device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lane& L, Body&& body) {
+  constexpr int NW = S::TILE / 64;
+  uint32_t* const tab = c.dtab;
+  const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.wtot_w[D * NW]);   // items of this wavefront
+  const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cnt[D]);         // tile-local row of its first item
+  uint32_t carry[SCtx<S>::K1];                               // running tile-local byte offset of the body's string columns
+  static_for<0, S::K>([&](auto ik) {
+    constexpr int k = decltype(ik)::value;
+    if constexpr (S::dense_body(LID, k)) carry[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cnt[k]);
+  });
+  uint32_t& rm = c.remaining(DEPTH);
+  bool inlist = L.live;                                      // h_list_begin: the row carries a list
+  for (uint32_t lo = 0;; lo += kDenseCap) {
+    const uint32_t limit = lo + kDenseCap;
+    // phase A, one lane = one record: note where the items [lo, limit) of the wave start
+    for (;;) {
+      const bool need = inlist && rm == 0;                   // at a block boundary: count, or the 0 terminator
+      uint32_t raw, n;
+      (void)varint16(src.ld4(L.cur), 4u, raw, n);
+      if (need) {
+        L.cur += n;
+        if ((raw >> 1) == 0) inlist = false;
+        else rm = raw >> 1;
+      }
+      const uint32_t idx = c.cnt[D] - wbase;                 // row of this lane's next item, relative to the wave's first
+      const bool go = inlist && idx < limit;
+      if (!__any(go)) break;
+      if (go) tab[idx - lo] = L.cur;
+      L.live = go; L.pres = go;
+      body(IC<0>{}, SkipCtx<SCtx<S>>(c), L);
+      if (go) { rm -= 1; c.cnt[D] += 1; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // a wave's DS instructions execute in order: no barrier
+    // phase B, one lane = one item
+    const uint32_t nr = n_w > lo ? (n_w - lo < (uint32_t)kDenseCap ? n_w - lo : (uint32_t)kDenseCap) : 0u;
+    for (uint32_t g = 0; g < nr; g += 64) {
+      const uint32_t i = g + c.lane;
+      const bool act = i < nr;
+      Lane Li;
+      Li.live = act; Li.pres = act; Li.err = 0; Li.edetail = 0; Li.redo = false;
+      Li.pstk = 0; Li.lstk = 0; Li.sstk = 0;
+      Li.cur = act ? tab[i] : 0u;
+      Li.end = 0xFFFFFFFFu;
+      SCtx<S> ci = c;
+      ci.cnt[D] = wbase + lo + i;
+      {   // item sizes -> offsets of every item inside the body's string columns
+        SCtx<S> cz = c;
+        static_for<0, S::K>([&](auto ik) {
+          constexpr int k = decltype(ik)::value;
+          if constexpr (S::dense_body(LID, k)) cz.cnt[k] = 0;
+        });
+        Lane Lz = Li;
+        body(IC<0>{}, SkipCtx<SCtx<S>>(cz), Lz);
+        static_for<0, S::K>([&](auto ik) {
+          constexpr int k = decltype(ik)::value;
+          if constexpr (S::dense_body(LID, k)) {
+            const uint32_t d = cz.cnt[k];
+            const uint32_t incl = wave_incl_scan(d, c.lane);
+            ci.cnt[k] = carry[k] + incl - d;
+            carry[k] += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          }
+        });
+      }
+      body(IC<1>{}, ci, Li);
+    }
+    if (limit >= n_w) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  L.live = false; L.pres = false;                            // (h_list_end restores both from the stacks)
+}
 
 // CAREFUL = false: the branch-free fast walk out of the LDS window (walk.h `reject`); tiles whose window does not
 // fit LDS are always walked carefully, straight from global memory.
@@ -189,6 +285,7 @@ __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, cons
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
   c.nullcnt = s.nullcnt; c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
+  c.dtab = s.dtab + (tid >> 6) * kDenseCap; c.wtot_w = s.wtot + (tid >> 6);
 }
 
 // --------------------------------------------------------------------------

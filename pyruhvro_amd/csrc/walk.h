@@ -261,7 +261,8 @@ __device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_
 // The emit kernel only takes the fast walk for tiles whose size pass (same predicates, same bytes) met no anomaly in
 // any lane (tileflag bit 1 clear), so in <EMIT, !CAREFUL> the anomaly predicates are dead weight: reject() and
 // everything that only feeds it drop out (measured on MI355X: k_emit 0.950 -> 0.918 ms, profiles/r02a_variants_ab.txt).
-#define RH_TRUST (EMIT && !CAREFUL)
+// (Ctx::kSkip: the same holds for the size-like sub-walks the emit kernel runs inside such a tile -- SkipCtx below.)
+#define RH_TRUST ((EMIT && !CAREFUL) || Ctx::kSkip)
 #define RH_REJECT(L, ...) do { if constexpr (!RH_TRUST) reject<CAREFUL>(L, __VA_ARGS__); } while (0)
 
 // --------------------------------------------------------------------------
@@ -420,6 +421,31 @@ template <class Ctx>
 __device__ __forceinline__ uint32_t row_of(const Ctx& c, int dom) {
   return dom == 0 ? c.lrow : c.gbase(dom - 1) + c.counter(dom - 1);
 }
+
+// View of a context for the counters-only (EMIT = false) walk of bytes the size pass has already cleared: every
+// anomaly predicate drops out (RH_TRUST).  Used by the emit kernel's item-dense list handling (spec_body.h dense_list)
+// to find item boundaries and item sizes without emitting anything.
+template <class C>
+struct SkipCtx {
+  static constexpr bool kSkip = true;
+  static constexpr bool kWide = C::kWide;
+  const C& base;
+  const uint32_t* sym_off;
+  const uint8_t* sym_data;
+  uint32_t lrow, lane;
+  bool wave_live;
+  __device__ __forceinline__ explicit SkipCtx(const C& b)
+      : base(b), sym_off(b.sym_off), sym_data(b.sym_data), lrow(b.lrow), lane(b.lane), wave_live(b.wave_live) {}
+  __device__ __forceinline__ uint32_t& counter(int id) const { return base.counter(id); }
+  __device__ __forceinline__ uint32_t& remaining(int d) const { return base.remaining(d); }
+  // (the EMIT side of the handlers is dead code under EMIT = false, but it has to compile)
+  __device__ __forceinline__ void* buf(int id) const { return base.buf(id); }
+  __device__ __forceinline__ uint32_t gbase(int id) const { return base.gbase(id); }
+  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { base.add_nulls_wave(node, n); }
+  __device__ __forceinline__ void add_nulls_lane(int node) const { base.add_nulls_lane(node); }
+  __device__ __forceinline__ void put_word0(int b, uint64_t m) const { base.put_word0(b, m); }
+  __device__ __forceinline__ void set_bit(int b, int dom, uint32_t row) const { base.set_bit(b, dom, row); }
+};
 
 // validity bit + null count of one row (the buffer exists iff F_CAN_NULL)
 template <bool EMIT, class Ctx>
