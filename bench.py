@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--stats-every", type=int, default=STATS_EVERY,
                     help="every Nth timed step carries the kernels' HIP-event timestamps (costs such a step ~30 us)")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--sync-calls", action="store_true", help="every step waits for its own call (no RH_ASYNC pipelining)")
+    ap.add_argument("--no-projection", action="store_true", help="skip config5_projection (profiler passes: only full-size launches)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="records of the CPU baseline (0 = the whole workload)")
     ap.add_argument("--direction", default="decode", choices=["decode", "encode"],
@@ -208,8 +210,10 @@ def run(args, make_step=None, backend="nccl"):
         if use_cuda:
             torch.cuda.synchronize()
 
+    drain = getattr(step, "drain", lambda: [])
     for _ in range(args.warmup):
         step()
+    drain()
     sync()
     t0 = time.perf_counter()
     # Kernel durations come from the kernels' own start / stop timestamps (HIP events handed to the launches by the
@@ -217,13 +221,25 @@ def run(args, make_step=None, backend="nccl"):
     # timed region every STATS_EVERY-th step is a timed launch and the others run exactly as a product call does.
     acc = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0}
     sampled = 0
-    for i in range(args.steps):
-        want = i % max(getattr(args, "stats_every", STATS_EVERY), 1) == 0
-        st = step(want) if use_cuda else step()
-        if want or not use_cuda:
+    # A step = one rh_decode_device call, made with RH_ASYNC: the call is on the stream when the C entry point returns and
+    # is settled (rh_device_result_wait: error check, row / null counts; then freed) PIPELINE_DEPTH steps later, so the GPU
+    # has the next call queued while this one drains -- every step's full work, its control-word read-back and its settle
+    # are inside the timed region; only the host's waiting is overlapped.  `sync_call_ms` in the line is the same call made
+    # synchronously (one call, one wait), back to back.
+    def take(stats_list):
+        nonlocal sampled
+        for st in stats_list:
             sampled += 1
             for k in acc:
                 acc[k] += st.get(k, 0.0)
+    for i in range(args.steps):
+        want = i % max(getattr(args, "stats_every", STATS_EVERY), 1) == 0
+        st = step(want) if use_cuda else step()
+        if isinstance(st, dict):
+            take([st])
+        elif st:
+            take(st)
+    take(drain())
     sync()
     wall = time.perf_counter() - t0
     wall = rdist.max_over_ranks(wall, dev)
@@ -237,6 +253,48 @@ def run(args, make_step=None, backend="nccl"):
     per_rank = rdist.gather_stats(local, dev)
     agg = rdist.aggregate(per_rank, args.steps, wall)
     return rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc)
+
+
+PIPELINE_DEPTH = 3      # asynchronous calls in flight before the oldest is settled and freed
+SYNC_CALLS = False      # --sync-calls: every step waits for its own call (the pre-RH_ASYNC behaviour)
+
+
+class Pipeline:
+    """Asynchronous rh_decode_device calls, settled PIPELINE_DEPTH submissions later (bounded device memory: each
+    unsettled call owns its arena and workspace)."""
+
+    def __init__(self, call, info):
+        import collections
+        self.call, self.info, self.ring = call, info, collections.deque()
+
+    def _retire(self):
+        h, want = self.ring.popleft()
+        try:
+            self.call.wait(h, want)          # raises on a malformed record, like the synchronous call
+            st = None
+            if want:
+                st = self.call.stats.as_dict()
+                self.info["output_bytes"] = self.call.output_bytes(h)
+        finally:
+            self.call.free(h)
+        return st
+
+    def submit(self, want_stats):
+        self.ring.append((self.call.run(want_stats), want_stats))
+        out = []
+        while len(self.ring) > PIPELINE_DEPTH:
+            st = self._retire()
+            if st:
+                out.append(st)
+        return out
+
+    def drain(self):
+        out = []
+        while self.ring:
+            st = self._retire()
+            if st:
+                out.append(st)
+        return out
 
 
 def gpu_step_factory(gen_cfg, shard, dev, local_rank):
@@ -259,18 +317,15 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     data_len = int(offsets[-1])
     info = {"input_bytes": data_len, "output_bytes": 0}
 
-    # every ctypes argument is built once (cabi.PreparedDeviceDecode): a timed step is the C entry point + the free
+    # every ctypes argument is built once (cabi.PreparedDeviceDecode): a timed step is the C entry point, the wait and the free
     call = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
-                                     device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"])
+                                     device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"],
+                                     asynchronous=not SYNC_CALLS)
+    pipe = Pipeline(call, info)
 
     def step(want_stats=True):
-        h = call.run(want_stats)
-        st = None
-        if want_stats:
-            st = call.stats.as_dict()
-            info["output_bytes"] = call.output_bytes(h)
-        call.free(h)
-        return st
+        return pipe.submit(want_stats)
+    step.drain = pipe.drain
 
     def rank_step(world, rank=0):
         """The step rank `rank` of `world` would run on BASELINE config 5 (one list, whole reference chunks per GPU):
@@ -282,15 +337,33 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
         dl = int(offsets[sh["rows"]])
 
         c = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), dl, sh["rows"], schema, sh["chunks"],
-                                      device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=sh["chunk_rows"])
+                                      device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=sh["chunk_rows"],
+                                      asynchronous=not SYNC_CALLS)
+        p = Pipeline(c, {})
 
         def f():
-            c.free(c.run(False))
+            p.submit(False)
+        f.drain = p.drain
         return f, sh
+
+    def sync_call_ms(reps=30):
+        """The same call made synchronously (what a caller that needs the row counts before its next step pays)."""
+        c = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
+                                      device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"])
+        for _ in range(3):
+            c.free(c.run(False))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            c.free(c.run(False))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) * 1e3 / reps
+    step.sync_call_ms = sync_call_ms
 
     step.rank_step = rank_step
     step.keepalive = (d_data, d_off)
-    first = step()      # also fills output_bytes
+    step()
+    first = step.drain()[0]      # also fills output_bytes
     assert first["records"] == n
     info["specialized"] = int(first.get("specialized", 0))
     info["lds_bytes"] = int(first.get("lds_bytes", 0))
@@ -405,10 +478,12 @@ def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int
         f, sh = step.rank_step(g)
         for _ in range(5):
             f()
+        f.drain()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):
             f()
+        f.drain()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t) * 1e3 / reps
         out["g"][str(g)] = {"records_per_rank": sh["rows"], "chunks_per_rank": sh["chunks"], "ms_per_step": ms,
@@ -421,8 +496,9 @@ def main(argv=None):
     args = parse_args(argv)
     if args.direction == "encode":
         return encode_main(args)
-    global KERNEL
+    global KERNEL, SYNC_CALLS
     KERNEL = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
+    SYNC_CALLS = bool(args.sync_calls)
     import torch  # noqa: F401  (first: our library must share torch's HIP runtime)
     from avrogen.schemas import SCHEMAS
 
@@ -507,11 +583,14 @@ def main(argv=None):
                    "kernel_ms": {"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
                    "kernel_form": "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter",
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
+                   "calls": ("synchronous: every step waits for its own call" if SYNC_CALLS else
+                             f"RH_ASYNC, settled {PIPELINE_DEPTH} steps later (rh_device_result_wait), everything inside the timed region"),
+                   "sync_call_ms": run.step.sync_call_ms() if hasattr(run.step, "sync_call_ms") else None,
                    "path_kernel_ms": path_ms,
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": roofline,
     }
-    if world == 1 and shard_whole and hasattr(run.step, "rank_step"):
+    if world == 1 and shard_whole and hasattr(run.step, "rank_step") and not args.no_projection:
         out["config5_projection"] = config5_projection(run.step, wall * 1e3 / args.steps, num_chunks)
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n) if args.cpu_sample else n, num_chunks)

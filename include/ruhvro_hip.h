@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 3
+#define RH_ABI_VERSION 4
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -89,6 +89,16 @@ typedef struct {
 #define RH_KERNEL_AUTO 0
 #define RH_KERNEL_GENERIC 1
 #define RH_KERNEL_SPECIALIZED 2
+/* rh_decode_device only (ABI version 4), OR-ed into rh_opts.flags: return as soon as the call is ON THE STREAM (size
+ * pass, scan + arena layout, emit pass and the read-back of its control words all enqueued), without waiting for it.
+ * The result's device buffers are valid in stream order on rh_opts.stream, like any asynchronous HIP work; what the
+ * HOST learns from a call -- the first malformed record (the in-order join of deserialize.rs:115-119), row counts,
+ * null counts, an arena that has to be re-laid-out -- is settled by rh_device_result_wait(), which every accessor of
+ * an unsettled result also runs first.  The input buffers must stay alive until then.  A schema's first call on a
+ * device (no size history to reserve the arena from) completes synchronously whatever the flag says.  This is how a
+ * pipeline of small batches keeps the GPU busy: a 1M-record call is 0.15 ms of kernels, and a synchronous call adds
+ * ~25 us of host turn-around during which the GPU idles. */
+#define RH_ASYNC 8
 
 struct rh_stats {
   uint64_t records;
@@ -134,6 +144,11 @@ typedef struct rh_device_result rh_device_result;
 int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offsets,
                      uint64_t data_len, uint64_t n, uint64_t num_chunks, const rh_opts* opts,
                      rh_device_result** out, rh_stats* stats, char** err);
+/* Settle an RH_ASYNC call: waits for its stream, returns what the synchronous call would have returned (RH_OK, or
+ * RH_ERR_DECODE with the reference's message for the lowest malformed record ...).  `stats` (optional) receives the
+ * stage timings when the call was made with a non-NULL stats argument (which is itself not written by an asynchronous
+ * call).  A no-op returning RH_OK on a result that is already settled.  Not thread-safe per result. */
+int rh_device_result_wait(rh_device_result* r, rh_stats* stats, char** err);
 uint32_t rh_device_result_chunks(const rh_device_result* r);
 /* Exact (unpadded) Arrow buffer bytes the call produced, all chunks. */
 uint64_t rh_device_result_output_bytes(const rh_device_result* r);

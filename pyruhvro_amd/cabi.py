@@ -101,6 +101,7 @@ def lib():
         L.rh_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(RhOpts), C.POINTER(C.c_void_p), C.POINTER(RhStats),
                                        C.POINTER(C.c_char_p)]
+        L.rh_device_result_wait.argtypes = [C.c_void_p, C.POINTER(RhStats), C.POINTER(C.c_char_p)]
         L.rh_device_result_chunks.restype = C.c_uint32
         L.rh_device_result_chunks.argtypes = [C.c_void_p]
         L.rh_device_result_output_bytes.restype = C.c_uint64
@@ -189,6 +190,7 @@ def _import_chunks(arr, k: int, schema: pa.Schema) -> List[pa.RecordBatch]:
 
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+RH_ASYNC = 8      # rh_opts.flags: rh_decode_device returns once the call is on the stream (rh_device_result_wait settles it)
 
 
 def kernel_source(schema_json: str) -> str:
@@ -321,6 +323,17 @@ class DeviceResult:
             raise RuntimeError("rh_device_result_export failed")
         return out
 
+    def wait(self) -> "DeviceResult":
+        """rh_device_result_wait: settle an asynchronous call (raises what the synchronous call would have raised)."""
+        st = RhStats()
+        err = C.c_char_p()
+        rc = lib().rh_device_result_wait(self.handle, C.byref(st), C.byref(err))
+        if rc != RH_OK:
+            _raise(rc, err)
+        if getattr(self, "_want_stats", False) and st.records:
+            self.stats = st.as_dict()
+        return self
+
     def to_host(self) -> List[pa.RecordBatch]:
         k = self.chunks
         arr = (ArrowArray * k)()
@@ -411,20 +424,23 @@ def encode_device(batch_array_addr: int, batch_schema_addr: int, schema_json: st
 
 def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
                   device: int = -1, stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO,
-                  chunk_rows: int = 0) -> DeviceResult:
+                  chunk_rows: int = 0, asynchronous: bool = False) -> DeviceResult:
     """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr()).  chunk_rows: explicit geometry
-    for a range of a larger call's chunks (rh_opts.chunk_rows)."""
+    for a range of a larger call's chunks (rh_opts.chunk_rows).  asynchronous: RH_ASYNC -- the result is returned
+    unsettled (DeviceResult.wait() settles it and fills .stats; every accessor settles implicitly)."""
     L = lib()
     s = Schema.get(schema_json)
     out = C.c_void_p()
     st = RhStats()
     err = C.c_char_p()
-    opts, _keep = make_opts(device, kernel, stream, None, chunk_rows)
+    opts, _keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0), stream, None, chunk_rows)
     rc = L.rh_decode_device(s.handle, d_data, d_offsets, data_len, n, num_chunks, C.byref(opts), C.byref(out),
                             C.byref(st) if want_stats else None, C.byref(err))
     if rc != RH_OK:
         _raise(rc, err)
-    return DeviceResult(out.value, s, st.as_dict())
+    r = DeviceResult(out.value, s, st.as_dict())
+    r._want_stats = want_stats
+    return r
 
 
 class PreparedDeviceDecode:
@@ -434,10 +450,11 @@ class PreparedDeviceDecode:
     every run(want_stats=True)."""
 
     def __init__(self, d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
-                 device: int = -1, stream: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0):
+                 device: int = -1, stream: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0, asynchronous: bool = False):
         self._L = lib()
         self._schema = Schema.get(schema_json)
-        self._opts, self._keep = make_opts(device, kernel, stream, None, chunk_rows)
+        self._opts, self._keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0), stream, None, chunk_rows)
+        self._wait = self._L.rh_device_result_wait
         self.stats = RhStats()
         self._out = C.c_void_p()
         self._err = C.c_char_p()
@@ -453,6 +470,13 @@ class PreparedDeviceDecode:
         if rc != RH_OK:
             _raise(rc, self._err)
         return self._out.value
+
+    def wait(self, handle: int, want_stats: bool = False) -> None:
+        """Settle an asynchronous run() (rh_device_result_wait): raises what the synchronous call would have raised;
+        `stats` is refilled when the run asked for them."""
+        rc = self._wait(handle, self._st if want_stats else None, self._e)
+        if rc != RH_OK:
+            _raise(rc, self._err)
 
     def output_bytes(self, handle: int) -> int:
         return int(self._L.rh_device_result_output_bytes(handle))

@@ -47,6 +47,7 @@ int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
 int rh_launch_layout(const rh::LParams* L, void* stream);
+int rh_launch_publish(void* ctrl, void* host, uint32_t words, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
@@ -214,7 +215,8 @@ struct Lease {   // RAII pool block
 // more (2 us of fill kernel + the gap behind it, at the head of every call: profiles/r03e_timeline_*.txt).
 class CtrlPool {
  public:
-  struct Blk { void* p = nullptr; uint64_t size = 0; int device = 0; hipStream_t stream = nullptr; };
+  // clean: the call's last kernel (rh_k_publish) already left the block zeroed -- no memset on the way back
+  struct Blk { void* p = nullptr; uint64_t size = 0; int device = 0; hipStream_t stream = nullptr; bool clean = false; };
   Blk get(uint64_t size, int device, hipStream_t stream) {
     size = align_up(std::max<uint64_t>(size, 1), 4096);
     {
@@ -236,7 +238,8 @@ class CtrlPool {
   }
   void put(Blk b) {
     if (!b.p) return;
-    if (hipMemsetAsync(b.p, 0, b.size, b.stream) != hipSuccess) { (void)hipFree(b.p); return; }
+    if (!b.clean && hipMemsetAsync(b.p, 0, b.size, b.stream) != hipSuccess) { (void)hipFree(b.p); return; }
+    b.clean = false;
     Blk drop;
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -477,6 +480,7 @@ struct Timer {
 // ---------------------------------------------------------------------------
 // device result
 // ---------------------------------------------------------------------------
+struct rh_decode_call;                 // one device-resident decode call (DeviceDecode below), still on its stream
 struct rh_device_result {
   const CompiledSchema* cs = nullptr;
   int device = 0;
@@ -492,12 +496,19 @@ struct rh_device_result {
   uint64_t output_bytes = 0;           // exact (unpadded) Arrow bytes
   // The [buf][chunk] tables above are a pure function of (schema, chunk geometry, data_bytes).  A call whose arena was
   // laid out on the device (and accepted) leaves them to the first reader: tables() -- export, host copy, byte counts.
-  std::once_flag tables_once;
+  std::mutex tables_mu;
   bool tables_done = false;
+  // RH_ASYNC: the call is on its stream but the host has not looked at its outcome yet (settle(), below DeviceDecode)
+  std::unique_ptr<rh_decode_call> pending;
+  std::exception_ptr fail;             // what settle() found: every later accessor reports it again
+  rh_stats st;                         // stage timings of an asynchronous call that asked for them
+  bool has_stats = false;
 
+  rh_device_result();
+  ~rh_device_result();
   uint64_t rows(int dom, uint32_t c) const { return dom_rows[(size_t)dom * k + c]; }
   void fill_tables();                  // host statement of the layout rule (program.h buf_bytes / buf_slot_bytes)
-  void tables() { std::call_once(tables_once, [this] { if (!tables_done) fill_tables(); }); }
+  void tables() { std::lock_guard<std::mutex> g(tables_mu); if (!tables_done) fill_tables(); }
 };
 
 void rh_device_result::fill_tables() {
@@ -756,6 +767,33 @@ struct Events {
   float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
 };
 
+// "This call's work is done" markers of asynchronous calls (RH_ASYNC): hipStreamSynchronize would also wait for every
+// LATER call on the stream -- exactly the calls the asynchronous form exists to keep queued.  Recycled per device.
+struct DoneEvent {
+  hipEvent_t e = nullptr;
+  int device = 0;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::map<int, std::vector<hipEvent_t>>& idle() { static auto* v = new std::map<int, std::vector<hipEvent_t>>(); return *v; }
+  void record(int dev, hipStream_t s) {
+    device = dev;
+    {
+      std::lock_guard<std::mutex> g(mu());
+      auto& v = idle()[device];
+      if (!v.empty()) { e = v.back(); v.pop_back(); }
+    }
+    if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e, s));
+  }
+  void wait() { if (e) HIPCHK(hipEventSynchronize(e)); }
+  ~DoneEvent() {
+    if (!e) return;
+    std::lock_guard<std::mutex> g(mu());
+    auto& v = idle()[device];
+    if (v.size() < 64) v.push_back(e);
+    else (void)hipEventDestroy(e);
+  }
+};
+
 // Chunk geometry of a call that decodes a contiguous RANGE of another call's chunks (the pipelined host path):
 // k chunks of sz rows, the last one rows_last, instead of the split derived from (n, num_chunks).
 struct ChunkGeo {
@@ -781,132 +819,64 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   }
 }
 
-rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
-                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo) {
-  const CompiledSchema& cs = *s->cs;
-  Range rk("ruhvro_hip:decode_device (k_size, k_scan, k_layout, k_init, k_emit)");
+}  // namespace
+
+// One device-resident decode call.  enqueue() puts the whole call on the stream (k_size -> k_scan+k_layout -> k_init ->
+// k_emit -> one D2H of the control words) and finish() waits for it and settles the result (error check, arena
+// retry, host tables).  rh_decode_device runs both back to back; with RH_ASYNC the result is handed out between the
+// two and rh_device_result_wait() (or the first accessor that needs a host-side fact) runs finish(): the caller's next
+// call is on the stream before this one has drained, which is what a pipeline of small batches needs -- a 1M-record
+// call is 0.15 ms of kernels behind ~25 us of host turn-around (profiles/r03q_timeline_*.txt).
+struct rh_decode_call {
+  // the call
+  rh_schema* s;
+  const CompiledSchema& cs;
+  const uint8_t* d_data;
+  const uint64_t* d_offsets;
+  uint64_t data_len, n, num_chunks;
+  rh_opts opts;                 // by value: an asynchronous call outlives the caller's struct
+  bool want_stats;
+  rh_stats st;
+  rh_device_result& r;
   HostProf hp;
   int device = 0;
-  if (opts && opts->device >= 0) { HIPCHK(hipSetDevice(opts->device)); device = opts->device; }
-  else HIPCHK(hipGetDevice(&device));
-  hipStream_t stream = opts ? (hipStream_t)opts->stream : nullptr;
-  if ((uintptr_t)d_data & 15) throw std::invalid_argument("device payload pointer must be 16-byte aligned");
-
-  {   // the generic kernels' dynamic-LDS limit is a per-device function attribute: set it once per device
-    static std::mutex lds_mu;
-    static std::vector<int> lds_done;
-    std::lock_guard<std::mutex> g(lds_mu);
-    if (std::find(lds_done.begin(), lds_done.end(), device) == lds_done.end()) {
-      if (rh_set_max_lds(160 * 1024) != 0) throw HipError("cannot raise the dynamic LDS limit of the decode kernels");
-      lds_done.push_back(device);
-    }
-  }
-
-  auto res = std::make_unique<rh_device_result>();
-  rh_device_result& r = *res;
-  r.cs = &cs;
-  r.device = device;
-  r.n = n;
-  ChunkGeo ogeo;
-  if (!geo && opts && opts->chunk_rows) {   // a range of a larger call's chunks (one process per GPU): rh_opts.chunk_rows
-    if (num_chunks < 1 || num_chunks > 0xFFFFFFFFull || (num_chunks - 1) > n / opts->chunk_rows ||
-        (n > 0 && n == (num_chunks - 1) * opts->chunk_rows && num_chunks > 1))
-      throw std::invalid_argument("chunk_rows: the n records do not make num_chunks chunks of chunk_rows rows (the last one takes the rest)");
-    ogeo.k = (uint32_t)num_chunks;
-    ogeo.sz = opts->chunk_rows;
-    ogeo.rows_last = n - (num_chunks - 1) * opts->chunk_rows;
-    ogeo.payload_bytes = data_len;
-    geo = &ogeo;
-  }
-  const uint32_t k = geo ? geo->k : rh_clamp_chunks(n, num_chunks);
-  r.k = k;
-  r.sz = geo ? geo->sz : n / k;
-  r.rows_last = geo ? geo->rows_last : n - (uint64_t)(k - 1) * r.sz;
-  const int K = cs.K, nnodes = (int)cs.nodes.size(), nbuf = (int)cs.bufs.size();
-  const DeviceProgram& dp = device_program(s, device);
-
-  // kernel form: schema-specialised (compiled once per schema, cached) or the generic interpreter
-  const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
+  hipStream_t stream = nullptr;
+  ChunkGeo geo_v;
+  const ChunkGeo* geo = nullptr;
+  // derived
+  uint32_t k = 1;
+  int K = 0, nnodes = 0, nbuf = 0;
+  const DeviceProgram* dp = nullptr;
   const SpecKernel* sk = nullptr;
-  // the specialised kernels address every chunk buffer with 32-bit byte offsets
-  // (every chunk buffer below 4 GiB: at most max_row_bytes per row -- 16 unless the schema has a wider fixed)
-  // (RUHVRO_HIP_NARROW_ROWS: test hook that lowers the bound so that small inputs take the wide-index fallback)
-  const uint64_t narrow_rows = (uint64_t)env_long("RUHVRO_HIP_NARROW_ROWS",
-                                                  (long)std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16)), 1, 1l << 28);
-  const bool narrow_ok = std::max(r.sz, r.rows_last) < narrow_rows;
-  if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
-    const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
-    const SpecKernel& k0 = spec_kernel(s, device, may_compile);
-    if (k0.ok) sk = &k0;
-    else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
-  }
-  const uint64_t tile = sk ? (uint64_t)rh::spec_tile_records() : (uint64_t)rh::kBlock;   // records per workgroup
-  const uint64_t bpc64 = std::max<uint64_t>((r.sz + tile - 1) / tile, 1);
-  const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + tile - 1) / tile;
-  if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
-  const uint32_t nblocks = (uint32_t)nblocks64;
-
-
-  // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
-  const uint64_t o_null = 32;     // control words first (program.h): first_bad, layout flag, arena bytes used
-  const uint64_t o_tot = align_up(o_null + 4ull * nnodes * k, 8);
-  const uint64_t ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
-  const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
-  const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
-  const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
-  const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
-  const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
-  const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((K + 1) / 2) * nblocks * tile : 0), kAlign);
-  hp.mark("setup");
-  Lease ws(dev_pool(), ws_bytes, device);
-  Lease hctrl(pin_pool(), ctrl_bytes, device);
-  CtrlLease ctrl(ctrl_bytes, device, stream);        // all zero (CtrlPool)
-  hp.mark("leases");
-
+  uint64_t narrow_rows = 0, tile = 0, bpc64 = 0, payload = 0;
+  uint32_t nblocks = 0;
+  uint64_t o_null = 32, o_tot = 0, ctrl_bytes = 0;
+  Lease ws, hctrl, dtab, prof_buf;
+  std::unique_ptr<CtrlLease> ctrl;
   rh::KParams P;
-  std::memset(&P, 0, sizeof P);
-  P.data = d_data; P.offsets = d_offsets; P.data_len = data_len;
-  P.n = n; P.sz = r.sz; P.rows_last = r.rows_last; P.k = k; P.bpc = (uint32_t)bpc64; P.nblocks = nblocks;
-  P.prog = dp.prog; P.sym_off = dp.sym_off; P.sym_data = dp.sym_data;
-  P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
-  P.nbuf = nbuf; P.cnt_databuf = dp.cnt_databuf;
-  P.first_bad = (unsigned long long*)ctrl.ptr();
-  P.nullcount = (uint32_t*)(ctrl.ptr() + o_null);
-  P.totals = (uint64_t*)(ctrl.ptr() + o_tot);
-  P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
-  P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
-  P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
-  P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
-  P.lanecnt = (uint32_t*)(ws.ptr() + o_lcnt);
+  uint32_t lds_bytes = 0, emit_lds = 0;
+  bool profile = false;
+  Events ev;
+  std::vector<uint64_t> totals;
+  uint64_t n_entries = 0, tab_bytes = 0;
+  uint64_t* d_sizes = nullptr;
+  uint64_t exact = 0;
+  bool child_bitmaps = false, fused = false, timed_size = false;
+  double basis = 0;
+  bool settled = false;         // finish() ran (or the call completed inside enqueue())
+  bool async = false;           // RH_ASYNC: mark the end of this call's work on the stream (DoneEvent)
+  DoneEvent done;
 
-  // LDS: fixed part + input window sized from the mean record length (falls back to global reads
-  // for workgroups whose 256 records do not fit)
-  const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
-  const uint64_t payload = geo ? geo->payload_bytes : data_len;
-  const uint64_t avg = n ? payload / n + 1 : 16;
-  // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD)
-  const uint64_t win_pct = (uint64_t)env_long("RUHVRO_HIP_WIN_PCT", 115, 100, 400);
-  const uint64_t win_pad = (uint64_t)env_long("RUHVRO_HIP_WIN_PAD", 2048, 0, 65536);
-  uint64_t win = align_up(avg * tile * win_pct / 100 + win_pad * tile / rh::kBlock, 16);
-  win = std::max<uint64_t>(win, 8192 * tile / rh::kBlock);
-  const uint64_t lds_cap = 160 * 1024 - 512;
-  if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
-  win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
-  P.win_bytes = (uint32_t)win;
-  const uint32_t lds_bytes = lds_fixed + (uint32_t)win;
-  // optional in-kernel phase timing of the specialised kernels (RUHVRO_HIP_PROFILE=1)
-  static const bool profile = [] { const char* e = std::getenv("RUHVRO_HIP_PROFILE"); return e && *e && *e != '0'; }();
-  Lease prof_buf;
-  if (profile && sk) {
-    prof_buf = Lease(dev_pool(), 64 * 32 * 8, device);
-    HIPCHK(hipMemsetAsync(prof_buf.ptr(), 0, 64 * 32 * 8, stream));
-    P.prof = (unsigned long long*)prof_buf.ptr();
+  rh_decode_call(rh_schema* s_, const uint8_t* data, const uint64_t* offs, uint64_t dl, uint64_t n_, uint64_t nc, const rh_opts* o,
+               bool stats, const ChunkGeo* g, rh_device_result& res)
+      : s(s_), cs(*s_->cs), d_data(data), d_offsets(offs), data_len(dl), n(n_), num_chunks(nc), opts(o ? *o : default_opts()),
+        want_stats(stats), r(res) {
+    std::memset(&st, 0, sizeof st);
+    if (g) { geo_v = *g; geo = &geo_v; }
+    opts.devices = nullptr; opts.n_devices = 0; opts.device_stats = nullptr;   // (not used below; never dangling)
   }
 
-  Events ev;
-  if (stats) ev.init();
-  hp.mark("events");
-  auto check_bad = [&](const uint8_t* h) {
+  void check_bad(const uint8_t* h) {
     unsigned long long fb = *(const unsigned long long*)h;
     if (!fb) return;
     const uint64_t rec = ~fb;
@@ -915,24 +885,10 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
     rh::ErrInfo ei;
     HIPCHK(hipMemcpy(&ei, P.errinfo + b, sizeof ei, hipMemcpyDeviceToHost));
     throw DecodeError(format_error(ei));
-  };
-
-  // ---- the launch sequence.  With a size history for this schema the whole call is ONE stream submission:
-  //   k_size -> k_scan -> k_layout (exact arena layout on the device, program.h LParams) -> k_init -> k_emit -> one D2H
-  // of the control words.  The arena is reserved up front from the history; when it turns out too small (the data
-  // changed character), the layout kernel says so, init/emit return at once, and the host re-runs the tail with an
-  // exactly sized arena -- which is also what the first call of a schema does.
-  std::vector<uint64_t> totals((size_t)K * k, 0);
-  const uint64_t n_entries = (uint64_t)k * std::max(nbuf, 0);
-  const uint64_t tab_bytes = align_up((uint64_t)std::max(nbuf, 1) * k * 16, kAlign);
-  Lease dtab(dev_pool(), tab_bytes, device);
-  uint64_t* const d_sizes = (uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
-  P.bufptr = (void* const*)dtab.ptr();
-  uint64_t exact = 0;
-  uint32_t emit_lds = 0;
+  }
 
   // host statement of the layout (same rule, same table order as rh_k_layout): fills the result's tables
-  auto layout_host = [&]() {
+  void layout_host() {
     r.data_bytes = totals;
     for (auto t : totals)
       if (t > 0x7FFFFFFFull) {
@@ -945,12 +901,11 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
           if (totals[(size_t)(d - 1) * k + c] >= narrow_rows) throw NeedWideIndex();
     r.fill_tables();
     exact = r.output_bytes;
-  };
-  bool child_bitmaps = false;     // bitmaps of child row domains are built with atomics on zeroed words
-  for (const rh::BufDesc& d : cs.bufs) child_bitmaps = child_bitmaps || (d.kind == rh::BK_BITMAP && d.dom != 0);
-  auto launch_tail = [&](bool offsets_done) {     // k_init + k_emit through the device tables at dtab
+  }
+
+  void launch_tail(bool offsets_done) {     // k_init + k_emit through the device tables at dtab
     if (nbuf > 0 && (child_bitmaps || !offsets_done) &&
-        rh_launch_init(P.bufptr, d_sizes, dp.desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
+        rh_launch_init(P.bufptr, d_sizes, dp->desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
     if (n > 0) {
       emit_lds = lds_bytes;
       if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4))
@@ -960,8 +915,10 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
       ev.rec(3, stream);
       ev.rec(4, stream);
     }
-  };
-  auto exact_tail = [&]() {      // totals are on the host: exactly sized arena, tables from the host
+  }
+
+  void exact_tail() {      // totals are on the host: exactly sized arena, tables from the host
+    ctrl->b.clean = false;
     layout_host();
     r.arena = Lease(dev_pool(), r.arena_bytes, device);
     Lease htab(pin_pool(), tab_bytes, device);
@@ -973,113 +930,342 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
         hsz[(size_t)c * nbuf + b] = r.buf_size[(size_t)b * k + c];
       }
     HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ctrl.ptr() + 8, 0, 8, stream));    // clear the layout flag (and the ticket) of a refused optimistic attempt
+    HIPCHK(hipMemsetAsync(ctrl->ptr() + 8, 0, 8, stream));    // clear the layout flag (and the ticket) of a refused optimistic attempt
     launch_tail(false);
-    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), o_tot, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), o_tot, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));      // also keeps htab alive until the table copy is done
     check_bad(hctrl.ptr());
-  };
-
-  const bool two_sync = env_long("RUHVRO_HIP_TWO_SYNC", 0, 0, 1) != 0;
-  // (RUHVRO_HIP_ARENA_PERMILLE: test hook, the arena is reserved as if the schema's history said that many output
-  //  bytes per 1000 input bytes -- a small value forces the LF_CAPACITY retry)
-  const long ratio_hook = env_long("RUHVRO_HIP_ARENA_PERMILLE", -1, 0, 1000000);
-  const double ratio = ratio_hook >= 0 ? std::max(1e-9, ratio_hook / 1000.0) : s->arena_ratio.load();
-  const bool fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
-  // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
-  // e3..e4 = k_emit
-  const bool timed_size = n > 0 && K > 0;
-  if (timed_size) {
-    if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
-           : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
-      throw HipError("k_size launch failed");
-    // (the single-submission path scans and lays the arena out in ONE launch, below)
-    if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
-  } else {
-    // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
-    P.all_careful = 1;
   }
-  hp.mark("size+scan_launch");
-  const double basis = (double)payload + 64.0 * (double)n;
-  if (fused) {
-    count(RH_CTR_FUSED_CALLS);
-    const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
-    r.arena = Lease(dev_pool(), capacity, device);
-    rh::LParams LP;
-    std::memset(&LP, 0, sizeof LP);
-    LP.totals = P.totals; LP.desc = dp.desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
-    LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
-    LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
-    LP.narrow_rows = narrow_rows;
-    if (timed_size ? rh_launch_scan_layout(&P, &LP, stream, ev.at(5), ev.at(2)) : rh_launch_layout(&LP, stream))
-      throw HipError("k_scan / k_layout launch failed");
-    launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
-    hp.mark("layout+emit_launch");
-    HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
-    hp.mark("d2h_enqueue");
-    HIPCHK(hipStreamSynchronize(stream));
-    hp.mark("sync");
-    check_bad(hctrl.ptr());
-    if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
-    const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
-    if (lflag & rh::LF_CAPACITY) {
-      count(RH_CTR_CAPACITY_RETRIES);
-      r.arena.release();
-      exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
-    } else if (lflag || stats) {
-      layout_host();                             // throws for LF_OFFSET32 / LF_NEED_WIDE: same tests on the same totals
-      if (lflag) throw HipError("internal error: layout kernel and host disagree");
-      if (r.arena_bytes != std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign)) throw HipError("internal error: device and host arena layouts differ");
+
+  void enqueue() {
+    Range rk("ruhvro_hip:decode_device (k_size, k_scan, k_layout, k_init, k_emit)");
+    if (opts.device >= 0) { HIPCHK(hipSetDevice(opts.device)); device = opts.device; }
+    else HIPCHK(hipGetDevice(&device));
+    stream = (hipStream_t)opts.stream;
+    if ((uintptr_t)d_data & 15) throw std::invalid_argument("device payload pointer must be 16-byte aligned");
+
+    {   // the generic kernels' dynamic-LDS limit is a per-device function attribute: set it once per device
+      static std::mutex lds_mu;
+      static std::vector<int> lds_done;
+      std::lock_guard<std::mutex> g(lds_mu);
+      if (std::find(lds_done.begin(), lds_done.end(), device) == lds_done.end()) {
+        if (rh_set_max_lds(160 * 1024) != 0) throw HipError("cannot raise the dynamic LDS limit of the decode kernels");
+        lds_done.push_back(device);
+      }
+    }
+
+    r.cs = &cs;
+    r.device = device;
+    r.n = n;
+    if (!geo && opts.chunk_rows) {   // a range of a larger call's chunks (one process per GPU): rh_opts.chunk_rows
+      if (num_chunks < 1 || num_chunks > 0xFFFFFFFFull || (num_chunks - 1) > n / opts.chunk_rows ||
+          (n > 0 && n == (num_chunks - 1) * opts.chunk_rows && num_chunks > 1))
+        throw std::invalid_argument("chunk_rows: the n records do not make num_chunks chunks of chunk_rows rows (the last one takes the rest)");
+      geo_v.k = (uint32_t)num_chunks;
+      geo_v.sz = opts.chunk_rows;
+      geo_v.rows_last = n - (num_chunks - 1) * opts.chunk_rows;
+      geo_v.payload_bytes = data_len;
+      geo = &geo_v;
+    }
+    k = geo ? geo->k : rh_clamp_chunks(n, num_chunks);
+    r.k = k;
+    r.sz = geo ? geo->sz : n / k;
+    r.rows_last = geo ? geo->rows_last : n - (uint64_t)(k - 1) * r.sz;
+    K = cs.K; nnodes = (int)cs.nodes.size(); nbuf = (int)cs.bufs.size();
+    dp = &device_program(s, device);
+
+    // kernel form: schema-specialised (compiled once per schema, cached) or the generic interpreter
+    const int mode = opts.flags & 3;
+    // the specialised kernels address every chunk buffer with 32-bit byte offsets
+    // (every chunk buffer below 4 GiB: at most max_row_bytes per row -- 16 unless the schema has a wider fixed)
+    // (RUHVRO_HIP_NARROW_ROWS: test hook that lowers the bound so that small inputs take the wide-index fallback)
+    narrow_rows = (uint64_t)env_long("RUHVRO_HIP_NARROW_ROWS",
+                                     (long)std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16)), 1, 1l << 28);
+    const bool narrow_ok = std::max(r.sz, r.rows_last) < narrow_rows;
+    if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
+      const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
+      const SpecKernel& k0 = spec_kernel(s, device, may_compile);
+      if (k0.ok) sk = &k0;
+      else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
+    }
+    tile = sk ? (uint64_t)rh::spec_tile_records() : (uint64_t)rh::kBlock;   // records per workgroup
+    bpc64 = std::max<uint64_t>((r.sz + tile - 1) / tile, 1);
+    const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + tile - 1) / tile;
+    if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
+    nblocks = (uint32_t)nblocks64;
+
+    // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
+    o_null = 32;     // control words first (program.h): first_bad, layout flag, arena bytes used
+    o_tot = align_up(o_null + 4ull * nnodes * k, 8);
+    ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
+    const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
+    const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
+    const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
+    const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
+    const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
+    const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((K + 1) / 2) * nblocks * tile : 0), kAlign);
+    hp.mark("setup");
+    ws = Lease(dev_pool(), ws_bytes, device);
+    hctrl = Lease(pin_pool(), ctrl_bytes, device);
+    ctrl.reset(new CtrlLease(ctrl_bytes, device, stream));        // all zero (CtrlPool)
+    hp.mark("leases");
+
+    std::memset(&P, 0, sizeof P);
+    P.data = d_data; P.offsets = d_offsets; P.data_len = data_len;
+    P.n = n; P.sz = r.sz; P.rows_last = r.rows_last; P.k = k; P.bpc = (uint32_t)bpc64; P.nblocks = nblocks;
+    P.prog = dp->prog; P.sym_off = dp->sym_off; P.sym_data = dp->sym_data;
+    P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
+    P.nbuf = nbuf; P.cnt_databuf = dp->cnt_databuf;
+    P.first_bad = (unsigned long long*)ctrl->ptr();
+    P.nullcount = (uint32_t*)(ctrl->ptr() + o_null);
+    P.totals = (uint64_t*)(ctrl->ptr() + o_tot);
+    P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
+    P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
+    P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
+    P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
+    P.lanecnt = (uint32_t*)(ws.ptr() + o_lcnt);
+
+    // LDS: fixed part + input window sized from the mean record length (falls back to global reads
+    // for workgroups whose 256 records do not fit)
+    const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
+    payload = geo ? geo->payload_bytes : data_len;
+    const uint64_t avg = n ? payload / n + 1 : 16;
+    // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD)
+    const uint64_t win_pct = (uint64_t)env_long("RUHVRO_HIP_WIN_PCT", 115, 100, 400);
+    const uint64_t win_pad = (uint64_t)env_long("RUHVRO_HIP_WIN_PAD", 2048, 0, 65536);
+    uint64_t win = align_up(avg * tile * win_pct / 100 + win_pad * tile / rh::kBlock, 16);
+    win = std::max<uint64_t>(win, 8192 * tile / rh::kBlock);
+    const uint64_t lds_cap = 160 * 1024 - 512;
+    if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
+    win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
+    P.win_bytes = (uint32_t)win;
+    lds_bytes = lds_fixed + (uint32_t)win;
+    // optional in-kernel phase timing of the specialised kernels (RUHVRO_HIP_PROFILE=1)
+    static const bool profile_env = [] { const char* e = std::getenv("RUHVRO_HIP_PROFILE"); return e && *e && *e != '0'; }();
+    profile = profile_env;
+    if (profile && sk) {
+      prof_buf = Lease(dev_pool(), 64 * 32 * 8, device);
+      HIPCHK(hipMemsetAsync(prof_buf.ptr(), 0, 64 * 32 * 8, stream));
+      P.prof = (unsigned long long*)prof_buf.ptr();
+    }
+
+    if (want_stats) ev.init();
+    hp.mark("events");
+
+    // ---- the launch sequence.  With a size history for this schema the whole call is ONE stream submission:
+    //   k_size -> k_scan -> k_layout (exact arena layout on the device, program.h LParams) -> k_init -> k_emit -> one D2H
+    // of the control words.  The arena is reserved up front from the history; when it turns out too small (the data
+    // changed character), the layout kernel says so, init/emit return at once, and the host re-runs the tail with an
+    // exactly sized arena -- which is also what the first call of a schema does.
+    totals.assign((size_t)K * k, 0);
+    n_entries = (uint64_t)k * std::max(nbuf, 0);
+    tab_bytes = align_up((uint64_t)std::max(nbuf, 1) * k * 16, kAlign);
+    dtab = Lease(dev_pool(), tab_bytes, device);
+    d_sizes = (uint64_t*)(dtab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
+    P.bufptr = (void* const*)dtab.ptr();
+    for (const rh::BufDesc& d : cs.bufs) child_bitmaps = child_bitmaps || (d.kind == rh::BK_BITMAP && d.dom != 0);   // built with atomics on zeroed words
+
+    const bool two_sync = env_long("RUHVRO_HIP_TWO_SYNC", 0, 0, 1) != 0;
+    // (RUHVRO_HIP_ARENA_PERMILLE: test hook, the arena is reserved as if the schema's history said that many output
+    //  bytes per 1000 input bytes -- a small value forces the LF_CAPACITY retry)
+    const long ratio_hook = env_long("RUHVRO_HIP_ARENA_PERMILLE", -1, 0, 1000000);
+    const double ratio = ratio_hook >= 0 ? std::max(1e-9, ratio_hook / 1000.0) : s->arena_ratio.load();
+    fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
+    // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
+    // e3..e4 = k_emit
+    timed_size = n > 0 && K > 0;
+    if (timed_size) {
+      if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
+             : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
+        throw HipError("k_size launch failed");
+      // (the single-submission path scans and lays the arena out in ONE launch, below)
+      if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
     } else {
-      // the device laid the arena out and accepted it: the host's tables (same rule, same totals) wait for their first
-      // reader (rh_device_result::tables) -- a caller that only hands the device buffers on never pays for them
-      r.data_bytes = totals;
-      r.arena_bytes = std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign);
+      // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
+      P.all_careful = 1;
     }
-  } else {
-    count(RH_CTR_TWO_SYNC_CALLS);
-    if (n > 0 && K > 0) {
-      HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl.ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-      check_bad(hctrl.ptr());
-      std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
+    hp.mark("size+scan_launch");
+    basis = (double)payload + 64.0 * (double)n;
+    if (fused) {
+      count(RH_CTR_FUSED_CALLS);
+      const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
+      r.arena = Lease(dev_pool(), capacity, device);
+      rh::LParams LP;
+      std::memset(&LP, 0, sizeof LP);
+      LP.totals = P.totals; LP.desc = dp->desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
+      LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
+      LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = sk ? 1u : 0u;
+      LP.narrow_rows = narrow_rows;
+      if (timed_size ? rh_launch_scan_layout(&P, &LP, stream, ev.at(5), ev.at(2)) : rh_launch_layout(&LP, stream))
+        throw HipError("k_scan / k_layout launch failed");
+      launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
+      hp.mark("layout+emit_launch");
+      // the control words go to the host from the call's last kernel, which also re-zeroes the block (rh_k_publish)
+      void* hdev = nullptr;
+      static const bool no_publish = env_long("RUHVRO_HIP_NO_PUBLISH", 0, 0, 1) != 0;
+      if (!no_publish && hipHostGetDevicePointer(&hdev, hctrl.ptr(), 0) == hipSuccess && hdev) {
+        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(ctrl_bytes / 4), stream)) throw HipError("k_publish launch failed");
+        ctrl->b.clean = true;
+      } else {
+        (void)hipGetLastError();
+        HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+      }
+      if (async) done.record(device, stream);
+      hp.mark("d2h_enqueue");
     }
-    exact_tail();
   }
-  if (n > 0 && basis > 0) {
-    const double slots = (double)n_entries * (double)kAlign;
-    s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
-  }
-  r.nullcount.assign((size_t)nnodes * k, 0);
-  std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
-  hp.mark("host_layout");
 
-  if (profile && sk) {
-    unsigned long long hr[64 * 32], h[32] = {0};
-    HIPCHK(hipMemcpy(hr, prof_buf.ptr(), sizeof hr, hipMemcpyDeviceToHost));
-    for (int r0 = 0; r0 < 64; r0++)
-      for (int i = 0; i < 32; i++) h[i] += hr[r0 * 32 + i];
-    const double waves = (double)nblocks * 4;
-    static const char* names[] = {"offsets", "stage+barrier", "lane_init", "walk1", "scan", "barrier", "layout", "walk2",
-                                  "errors+barrier", "flush"};
-    std::fprintf(stderr, "[ruhvro_hip profile] emit cycles/wave:");
-    for (int i = 0; i < 10; i++) std::fprintf(stderr, " %s=%.0f", names[i], h[i] / waves);
-    std::fprintf(stderr, "\n[ruhvro_hip profile] size cycles/wave: stage+barrier=%.0f init=%.0f walk=%.0f tail=%.0f | kernels ms: size=%.3f emit=%.3f\n",
-                 h[16] / waves, h[17] / waves, h[18] / waves, h[19] / waves, ev.ms(0, 1), ev.ms(3, 4));
+  void finish() {
+    if (settled) return;
+    settled = true;
+    HIPCHK(hipSetDevice(device));
+    if (fused) {
+      if (done.e) done.wait();                     // this call only: later calls stay queued behind it
+      else HIPCHK(hipStreamSynchronize(stream));
+      hp.mark("sync");
+      check_bad(hctrl.ptr());
+      if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
+      const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
+      if (lflag & rh::LF_CAPACITY) {
+        count(RH_CTR_CAPACITY_RETRIES);
+        r.arena.release();
+        exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
+      } else if (lflag || want_stats) {
+        layout_host();                             // throws for LF_OFFSET32 / LF_NEED_WIDE: same tests on the same totals
+        if (lflag) throw HipError("internal error: layout kernel and host disagree");
+        if (r.arena_bytes != std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign)) throw HipError("internal error: device and host arena layouts differ");
+      } else {
+        // the device laid the arena out and accepted it: the host's tables (same rule, same totals) wait for their first
+        // reader (rh_device_result::tables) -- a caller that only hands the device buffers on never pays for them
+        r.data_bytes = totals;
+        r.arena_bytes = std::max<uint64_t>(*(const uint64_t*)(hctrl.ptr() + 16), kAlign);
+      }
+    } else {
+      count(RH_CTR_TWO_SYNC_CALLS);
+      if (n > 0 && K > 0) {
+        HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        check_bad(hctrl.ptr());
+        std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
+      }
+      exact_tail();
+    }
+    if (n > 0 && basis > 0) {
+      const double slots = (double)n_entries * (double)kAlign;
+      s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
+    }
+    r.nullcount.assign((size_t)nnodes * k, 0);
+    std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
+    hp.mark("host_layout");
+
+    if (profile && sk) {
+      unsigned long long hr[64 * 32], h[32] = {0};
+      HIPCHK(hipMemcpy(hr, prof_buf.ptr(), sizeof hr, hipMemcpyDeviceToHost));
+      for (int r0 = 0; r0 < 64; r0++)
+        for (int i = 0; i < 32; i++) h[i] += hr[r0 * 32 + i];
+      const double waves = (double)nblocks * 4;
+      static const char* names[] = {"offsets", "stage+barrier", "lane_init", "walk1", "scan", "barrier", "layout", "walk2",
+                                    "errors+barrier", "flush"};
+      std::fprintf(stderr, "[ruhvro_hip profile] emit cycles/wave:");
+      for (int i = 0; i < 10; i++) std::fprintf(stderr, " %s=%.0f", names[i], h[i] / waves);
+      std::fprintf(stderr, "\n[ruhvro_hip profile] size cycles/wave: stage+barrier=%.0f init=%.0f walk=%.0f tail=%.0f | kernels ms: size=%.3f emit=%.3f\n",
+                   h[16] / waves, h[17] / waves, h[18] / waves, h[19] / waves, ev.ms(0, 1), ev.ms(3, 4));
+    }
+    if (want_stats) {
+      st.records = n;
+      st.input_bytes = payload;
+      st.output_bytes = exact;
+      st.chunks = k;
+      st.blocks = nblocks;
+      st.size_kernel_ms = timed_size ? ev.ms(0, 1) : 0.f;
+      st.scan_kernel_ms = timed_size ? ev.ms(5, 2) : 0.f;
+      st.emit_kernel_ms = n > 0 ? ev.ms(3, 4) : 0.f;
+      st.specialized = sk ? 1 : 0;
+      st.lds_bytes = emit_lds;
+    }
+    // the call's scratch goes back to the pools now (the control block is zeroed on its stream, CtrlPool)
+    ws.release(); dtab.release(); hctrl.release(); prof_buf.release(); ctrl.reset();
+  }
+
+  // a call that failed (or is abandoned) must not hand its blocks back while the GPU may still be using them
+  void drain() noexcept {
+    if (stream || device >= 0) { (void)hipSetDevice(device); (void)hipStreamSynchronize(stream); }
+  }
+};
+
+rh_device_result::rh_device_result() { std::memset(&st, 0, sizeof st); }
+rh_device_result::~rh_device_result() {
+  if (pending) {                 // freed without a wait: the GPU may still be writing into the blocks this result owns
+    pending->drain();
+    pending.reset();
+  }
+}
+
+namespace {
+typedef rh_decode_call DeviceDecode;
+
+rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
+                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo) {
+  auto res = std::make_unique<rh_device_result>();
+  auto call = std::make_unique<DeviceDecode>(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats != nullptr, geo, *res);
+  const bool async = opts && (opts->flags & RH_ASYNC) && !geo;
+  call->async = async;
+  try {
+    call->enqueue();
+    if (async && call->fused) {            // everything is on the stream: settle later (rh_device_result_wait)
+      res->pending = std::move(call);
+      return res.release();
+    }
+    call->finish();
+  } catch (...) {
+    call->drain();
+    throw;
   }
   if (stats) {
-    stats->records = n;
-    stats->input_bytes = payload;
-    stats->output_bytes = exact;
-    stats->chunks = k;
-    stats->blocks = nblocks;
-    stats->size_kernel_ms = timed_size ? ev.ms(0, 1) : 0.f;
-    stats->scan_kernel_ms = timed_size ? ev.ms(5, 2) : 0.f;
-    stats->emit_kernel_ms = n > 0 ? ev.ms(3, 4) : 0.f;
-    stats->specialized = sk ? 1 : 0;
-    stats->lds_bytes = emit_lds;
+    const float pack = stats->pack_ms, h2d = stats->h2d_ms, d2h = stats->d2h_ms, tot = stats->total_ms;
+    *stats = call->st;
+    stats->pack_ms = pack; stats->h2d_ms = h2d; stats->d2h_ms = d2h; stats->total_ms = tot;
   }
   return res.release();
+}
+
+
+// The host's half of an asynchronous call (RH_ASYNC): wait for the stream, check for a malformed record, retry with an
+// exact arena if the reserved one was too small, fall back to the generic kernels if a child row domain needs 64-bit
+// indexing.  Throws what the synchronous call would have thrown; a failed result stays failed.
+void settle(rh_device_result* r) {
+  if (r->fail) std::rethrow_exception(r->fail);
+  if (!r->pending) return;
+  std::unique_ptr<DeviceDecode> call = std::move(r->pending);
+  try {
+    try {
+      call->finish();
+      if (call->want_stats) { r->st = call->st; r->has_stats = true; }
+    } catch (const NeedWideIndex&) {
+      call->drain();
+      count(RH_CTR_WIDE_FALLBACKS);
+      rh_opts o = call->opts;
+      o.flags = RH_KERNEL_GENERIC;
+      rh_stats st2;
+      std::memset(&st2, 0, sizeof st2);
+      std::unique_ptr<rh_device_result> r2(decode_device_impl1(call->s, call->d_data, call->d_offsets, call->data_len, call->n,
+                                                               call->num_chunks, &o, call->want_stats ? &st2 : nullptr,
+                                                               call->geo));
+      call.reset();                                  // (its reference to *r ends here)
+      r->arena = std::move(r2->arena);
+      r->arena_bytes = r2->arena_bytes;
+      r->buf_off = std::move(r2->buf_off); r->buf_size = std::move(r2->buf_size); r->dom_rows = std::move(r2->dom_rows);
+      r->data_bytes = std::move(r2->data_bytes); r->nullcount = std::move(r2->nullcount);
+      r->output_bytes = r2->output_bytes; r->tables_done = r2->tables_done;
+      r->k = r2->k; r->sz = r2->sz; r->rows_last = r2->rows_last;
+      if (r2->has_stats || st2.records) { r->st = st2; r->has_stats = true; }
+    }
+  } catch (...) {
+    if (call) call->drain();
+    r->arena.release();
+    r->fail = std::current_exception();
+    throw;
+  }
 }
 
 // Device range -> freshly owned host memory.  Large results land in pooled PINNED memory (the copy then runs at PCIe
@@ -1114,6 +1300,7 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStrea
 }
 
 int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream = nullptr) {
+  settle(r);
   r->tables();
   Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
   slab->refs.store(1);   // guard while building
@@ -1352,7 +1539,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   const uint64_t n = r1 - r0;
   rh_opts o = default_opts();
   o.device = device;
-  o.flags = opts ? opts->flags : 0;
+  o.flags = opts ? (opts->flags & 3) : 0;      // kernel form only: the host paths settle every device call themselves
   o.stream = (void*)stream;
   float h2d = 0.f, pack_ms = 0.f;
   Lease din, pin;
@@ -1603,7 +1790,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
   std::vector<Turnstile> h2d_gates(gate_device.size()), d2h_gates(gate_device.size());
   const bool want = stats || (multi && opts->device_stats);
   rh_opts sopts = default_opts();
-  sopts.flags = opts ? opts->flags : 0;
+  sopts.flags = opts ? (opts->flags & 3) : 0;
   std::vector<std::thread> th;
   for (size_t g = 0; g < ns; g++) {
     th.emplace_back([&, g] {
@@ -1812,18 +1999,39 @@ uint32_t rh_device_result_chunks(const rh_device_result* r) { return r ? r->k : 
 
 uint64_t rh_device_result_output_bytes(const rh_device_result* r) {
   if (!r) return 0;
-  const_cast<rh_device_result*>(r)->tables();
+  try {
+    settle(const_cast<rh_device_result*>(r));
+    const_cast<rh_device_result*>(r)->tables();
+  } catch (...) {
+    return 0;                  // a failed asynchronous call produced nothing (rh_device_result_wait has the message)
+  }
   return r->output_bytes;
+}
+
+int rh_device_result_wait(rh_device_result* r, rh_stats* stats, char** err) {
+  if (!r) return RH_ERR_ARGUMENT;
+  return guarded(err, [&] {
+    settle(r);
+    if (stats && r->has_stats) *stats = r->st;
+    return RH_OK;
+  });
 }
 
 int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDeviceArray* out) {
   if (!r || !out || chunk >= r->k) return RH_ERR_ARGUMENT;
   std::memset(out, 0, sizeof *out);
-  r->tables();
-  export_chunk(*r, chunk, r->arena.ptr(), nullptr, &out->array);
+  try {
+    settle(r);
+    r->tables();
+    export_chunk(*r, chunk, r->arena.ptr(), nullptr, &out->array);
+  } catch (const DecodeError&) {
+    return RH_ERR_DECODE;
+  } catch (...) {
+    return RH_ERR_RUNTIME;
+  }
   out->device_id = r->device;
   out->device_type = ARROW_DEVICE_ROCM;
-  out->sync_event = nullptr;   // the producing stream was synchronised before the result was returned
+  out->sync_event = nullptr;   // the producing stream was synchronised before the result was settled
   return RH_OK;
 }
 

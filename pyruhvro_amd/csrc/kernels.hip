@@ -286,12 +286,22 @@ __device__ __forceinline__ void layout_body(const LParams& L, uint64_t* run_sum,
   uint32_t flag = 0;
   uint64_t mine = 0;
   for (uint32_t e = e0; e < e1; e++) mine += buf_slot_bytes(layout_entry(L, e, flag));
-  run_sum[tid] = mine;
+  // exclusive scan of the 256 run sums: 64-bit shuffle scan inside each wave, the four wave totals through LDS
+  // (a serial scan by thread 0 was ~2 us of the 7 us this kernel takes on its own -- a 1M-record flat-schema call)
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  uint64_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t up = __shfl_up(incl, d, 64);
+    if ((int)lane >= d) incl += up;
+  }
+  if (lane == 63) run_sum[wave] = incl;
   if (flag) atomicOr(&flags, flag);
   __syncthreads();
-  if (tid == 0) {          // 256 run sums: a serial exclusive scan is a few hundred cycles
-    uint64_t acc = 0;
-    for (int i = 0; i < kBlock; i++) { const uint64_t v = run_sum[i]; run_sum[i] = acc; acc += v; }
+  uint64_t wbase = 0;
+  for (uint32_t w = 0; w < wave; w++) wbase += run_sum[w];
+  if (tid == kBlock - 1) {
+    const uint64_t acc = wbase + incl;
     const uint64_t used = acc < kBufAlign ? kBufAlign : acc;
     uint32_t f = flags;
     if (used > L.capacity) f |= LF_CAPACITY;
@@ -301,7 +311,7 @@ __device__ __forceinline__ void layout_body(const LParams& L, uint64_t* run_sum,
   }
   __syncthreads();
   if (flags) return;       // nothing may be written through these tables: leave them alone
-  uint64_t off = run_sum[tid];
+  uint64_t off = wbase + incl - mine;
   uint32_t dummy = 0;
   for (uint32_t e = e0; e < e1; e++) {
     const uint64_t sz = layout_entry(L, e, dummy);
@@ -336,6 +346,20 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P,
   __syncthreads();
   if (!last) return;
   layout_body(L, run_sum, &flags);
+}
+
+// --------------------------------------------------------------------------
+// k_publish: the last launch of a call.  Hands the call's control block (first_bad, layout flag, arena bytes, null
+// counts, chunk totals -- a few hundred bytes to ~2 KB) to the host by storing it straight into pinned host memory,
+// and leaves the device copy ZEROED for the next call that leases it -- one ~2 us launch in place of a D2H blit kernel
+// (4.5 us) plus the fill kernel (1.7 us) that re-zeroed the block, which were 4-15 % of a 1M-record call
+// (profiles/r03s_timeline_*.txt).
+// --------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t words) {
+  for (uint32_t i = threadIdx.x; i < words; i += kBlock) {
+    host[i] = ctrl[i];
+    ctrl[i] = 0;
+  }
 }
 
 // true when the call must not emit: a malformed record was found by the size pass, or the layout kernel said no
@@ -441,6 +465,10 @@ extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, cons
                               uint32_t k, const unsigned long long* ctrl, void* stream) {
   hipLaunchKernelGGL(rh::rh_k_init, dim3(nbuf * k), dim3(rh::kBlock), 0, (hipStream_t)stream, bufptr, bufsize, desc,
                      nbuf, k, ctrl);
+  return (int)hipGetLastError();
+}
+extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t words, void* stream) {
+  hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, words);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
