@@ -278,6 +278,12 @@ __device__ __forceinline__ void e_bin_put(const Ctx& c, ELane& L, const Op op, c
     put_bytes<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf1)) + (uint64_t)c.row(op.dom) * W, W);
   } else if (op.a == BN_DEC_FIXED) {
     const uint32_t N = (uint32_t)op.b;                          // <= 16 (schema gate)
+    if (N < 16u) {      // the value must BE an N-byte two's complement number: bytes N..15 pure sign extension of byte N-1
+      const uint32_t sign = (bin_byte(v, N - 1) & 0x80u) ? 0xFFu : 0u;   // (the decoder is strict the other way: E_DECIMAL)
+      bool fits = true;
+      for (uint32_t j = N; j < 16u; j++) fits = fits && bin_byte(v, j) == sign;
+      if (!fits) { L.err = EE_DECIMAL; L.eop = (uint32_t)N; L.edetail = c.row(op.dom); return; }
+    }
     if (MODE == M_SIZE) { L.len += N; return; }
     for (uint32_t j = N; j-- > 0;) put_byte<MODE>(c, L, (uint8_t)bin_byte(v, j));
   } else if (op.a == BN_DEC_BYTES) {

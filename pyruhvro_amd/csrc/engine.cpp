@@ -2280,6 +2280,10 @@ std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, 
     }
     return "fast_encode: enum symbol '" + sym + "' not in schema";
   }
+  if (e.code == rh::EE_DECIMAL) {
+    std::snprintf(buf, sizeof buf, "decimal value at row %lld does not fit fixed(%u)", (long long)e.detail, e.pad);
+    return buf;
+  }
   std::snprintf(buf, sizeof buf, "encode error (code %u, op %u, detail %lld)", e.code, e.pad, (long long)e.detail);
   return buf;
 }

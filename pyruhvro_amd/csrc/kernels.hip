@@ -391,7 +391,10 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_init(void* const* bufp
 // --------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (call_aborted(P.first_bad)) return;
+  // Uniform for the workgroup: first_bad is only honoured when a size pass ran (K > 0) -- it is final before this kernel
+  // starts then; without a size pass this kernel is the one that writes it, and waves of one workgroup reading it at
+  // different times could disagree about returning ahead of the barriers below.  The layout flag is always final here.
+  if ((P.K > 0 && P.first_bad[0] != 0) || reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;
   const Smem s = carve(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Geo g = geometry(P, blockIdx.x);

@@ -360,8 +360,10 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
 template <class S>
 __device__ __forceinline__ void spec_emit(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // the size pass found a malformed record, or the layout kernel refused (program.h LayoutFlag): nothing to emit
-  if (P.first_bad[0] != 0 || reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;
+  // the size pass found a malformed record, or the layout kernel refused (program.h LayoutFlag): nothing to emit.
+  // (Both words are final before this kernel starts, so every wave of a workgroup takes the same side: without a size
+  //  pass -- K == 0 -- this kernel is the writer of first_bad and does not look at it.)
+  if ((S::K > 0 && P.first_bad[0] != 0) || reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;

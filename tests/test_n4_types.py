@@ -245,3 +245,30 @@ def test_gpu_error_texts(kernel):
             with pytest.raises(ValueError) as eo:
                 py_walker.decode(recs, js, extended=True)
             assert str(eo.value) == msg
+
+
+@pytest.mark.gpu
+def test_gpu_encode_refuses_a_decimal_that_does_not_fit_its_fixed(kernel):
+    """A Decimal128 on a fixed(N) base is written as its low N bytes.  Avro caps the precision of a fixed(N) decimal so
+    that every in-precision value fits, but Arrow does not police values against the precision: a batch whose raw 128-bit
+    value is not an N-byte two's complement number would silently decode to a different number -- the encoder refuses it
+    (lowest row wins), like e_enum_put refuses an unknown symbol; the decoder is strict the other way round (E_DECIMAL)."""
+    js = json.dumps({"type": "record", "name": "x", "fields": [
+        {"name": "a", "type": F("D2", 2, logicalType="decimal", precision=4, scale=0)}]})
+
+    def raw(vals):        # Decimal128(4, 0) from raw little-endian i128 values, in or out of precision
+        buf = b"".join(int(v).to_bytes(16, "little", signed=True) for v in vals)
+        arr = pa.Array.from_buffers(pa.decimal128(4, 0), len(vals), [None, pa.py_buffer(buf)])
+        return pa.RecordBatch.from_arrays([arr], names=["a"])
+
+    ok = [0, 1, -1, 9999, -9999, 127, -129, 32767, -32768]           # the last two: beyond precision 4, but 2-byte numbers
+    datums = [x for a in P.serialize_record_batch(raw(ok), js, 2) for x in a.to_pylist()]
+    assert datums[3] == b"\x27\x0f" and datums[6] == b"\xff\x7f" and datums[7] == b"\x7f\xff" and datums[8] == b"\x80\x00"
+    assert [int(v) for v in P.deserialize_array(datums, js).column("a").to_pylist()] == ok
+    for bad_row, bad in ((2, 32768), (5, -32769), (0, 10 ** 8)):
+        vals = list(ok)
+        vals[bad_row] = bad
+        vals[6] = 70000                                      # a later offender: the lowest row is the one reported
+        with pytest.raises(ValueError) as ei:
+            P.serialize_record_batch(raw(vals), js, 2)
+        assert str(ei.value) == "decimal value at row %d does not fit fixed(2)" % bad_row
