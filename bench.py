@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--stats-every", type=int, default=STATS_EVERY,
                     help="every Nth timed step carries the kernels' HIP-event timestamps (costs such a step ~30 us)")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the asynchronous steps are dealt to round-robin")
+    ap.add_argument("--overlap-streams", type=int, default=OVERLAP_STREAMS,
+                    help="streams of the second timed region reported as `overlapped` (0 = skip)")
     ap.add_argument("--sync-calls", action="store_true", help="every step waits for its own call (no RH_ASYNC pipelining)")
     ap.add_argument("--no-projection", action="store_true", help="skip config5_projection (profiler passes: only full-size launches)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
@@ -244,6 +247,26 @@ def run(args, make_step=None, backend="nccl"):
     wall = time.perf_counter() - t0
     wall = rdist.max_over_ranks(wall, dev)
 
+    # Second timed region (same K steps, same barriers): the steps dealt round-robin to OVERLAP_STREAMS HIP streams.
+    # Consecutive steps are independent batches, so the VALU-bound size pass of one runs beside the store-path-bound emit
+    # pass of another and small launches fill each other's tails.  Kernels that share the chip have no meaningful
+    # per-kernel duration, so `value` / `roofline` stay with the single-stream region above; this one is reported beside
+    # them (`overlapped`).
+    run.overlapped = None
+    if use_cuda and hasattr(step, "overlapped") and OVERLAP_STREAMS > 1 and not SYNC_CALLS:
+        ostep = step.overlapped(OVERLAP_STREAMS)
+        for _ in range(max(args.warmup, 2 * OVERLAP_STREAMS)):
+            ostep()
+        ostep.drain()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ostep()
+        ostep.drain()
+        sync()
+        owall = rdist.max_over_ranks(time.perf_counter() - t1, dev)
+        run.overlapped = {"streams": OVERLAP_STREAMS, "wall_s": owall, "ms_per_step": owall * 1e3 / args.steps}
+
     run.info = info
     run.step = step
     local = {"records": shard["rows"], "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
@@ -256,31 +279,37 @@ def run(args, make_step=None, backend="nccl"):
 
 
 PIPELINE_DEPTH = 3      # asynchronous calls in flight before the oldest is settled and freed
+STREAMS = 1             # --streams: HIP streams the steps of the MAIN timed region are dealt to round-robin (default: one)
+OVERLAP_STREAMS = 3     # --overlap-streams: streams of the second, `overlapped` timed region (0 / 1 = skip it)
 SYNC_CALLS = False      # --sync-calls: every step waits for its own call (the pre-RH_ASYNC behaviour)
 
 
 class Pipeline:
     """Asynchronous rh_decode_device calls, settled PIPELINE_DEPTH submissions later (bounded device memory: each
-    unsettled call owns its arena and workspace)."""
+    unsettled call owns its arena and workspace).  `calls`: one prepared call per stream, used round-robin (--streams:
+    consecutive steps are independent batches, so the size pass of one may run beside the tail of the previous emit)."""
 
-    def __init__(self, call, info):
+    def __init__(self, calls, info):
         import collections
-        self.call, self.info, self.ring = call, info, collections.deque()
+        self.calls = calls if isinstance(calls, (list, tuple)) else [calls]
+        self.info, self.ring, self.i = info, collections.deque(), 0
 
     def _retire(self):
-        h, want = self.ring.popleft()
+        call, h, want = self.ring.popleft()
         try:
-            self.call.wait(h, want)          # raises on a malformed record, like the synchronous call
+            call.wait(h, want)          # raises on a malformed record, like the synchronous call
             st = None
             if want:
-                st = self.call.stats.as_dict()
-                self.info["output_bytes"] = self.call.output_bytes(h)
+                st = call.stats.as_dict()
+                self.info["output_bytes"] = call.output_bytes(h)
         finally:
-            self.call.free(h)
+            call.free(h)
         return st
 
     def submit(self, want_stats):
-        self.ring.append((self.call.run(want_stats), want_stats))
+        call = self.calls[self.i % len(self.calls)]
+        self.i += 1
+        self.ring.append((call, call.run(want_stats), want_stats))
         out = []
         while len(self.ring) > PIPELINE_DEPTH:
             st = self._retire()
@@ -318,33 +347,52 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     info = {"input_bytes": data_len, "output_bytes": 0}
 
     # every ctypes argument is built once (cabi.PreparedDeviceDecode): a timed step is the C entry point, the wait and the free
-    call = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks,
-                                     device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"],
-                                     asynchronous=not SYNC_CALLS)
-    pipe = Pipeline(call, info)
+    extra = [torch.cuda.Stream(device=dev) for _ in range(max(STREAMS, 1) - 1)]
+    streams = [stream] + [x.cuda_stream for x in extra]
+
+    def prepared(dl, rows, chunks, chunk_rows, asynchronous):
+        return [cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), dl, rows, schema, chunks, device=local_rank,
+                                          stream=sx, kernel=KERNEL, chunk_rows=chunk_rows, asynchronous=asynchronous)
+                for sx in (streams if asynchronous else streams[:1])]
+    pipe = Pipeline(prepared(data_len, n, num_chunks, shard["chunk_rows"], not SYNC_CALLS), info)
 
     def step(want_stats=True):
         return pipe.submit(want_stats)
     step.drain = pipe.drain
 
-    def rank_step(world, rank=0):
+    def rank_step(world, rank=0, nstreams=1):
         """The step rank `rank` of `world` would run on BASELINE config 5 (one list, whole reference chunks per GPU):
         its rows of THIS list, the list's chunk geometry (rh_opts.chunk_rows).  Rank 0's rows are a prefix of the
-        buffers already in HBM."""
+        buffers already in HBM.  nstreams > 1: the steps dealt round-robin to that many streams (`overlapped`)."""
         from pyruhvro_amd import dist as rdist
         sh = rdist.strong_shard(n, num_chunks, world, rank)
         assert sh["row_lo"] == 0
         dl = int(offsets[sh["rows"]])
-
-        c = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), dl, sh["rows"], schema, sh["chunks"],
-                                      device=local_rank, stream=stream, kernel=KERNEL, chunk_rows=sh["chunk_rows"],
-                                      asynchronous=not SYNC_CALLS)
-        p = Pipeline(c, {})
+        xs = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+        calls = [cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), dl, sh["rows"], schema, sh["chunks"], device=local_rank,
+                                           stream=sx, kernel=KERNEL, chunk_rows=sh["chunk_rows"], asynchronous=not SYNC_CALLS)
+                 for sx in [stream] + [x.cuda_stream for x in xs]]
+        p = Pipeline(calls, {})
 
         def f():
             p.submit(False)
         f.drain = p.drain
+        f.keepalive = xs
         return f, sh
+
+    def overlapped(nstreams):
+        xs = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+        calls = [cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks, device=local_rank,
+                                           stream=sx, kernel=KERNEL, chunk_rows=shard["chunk_rows"], asynchronous=True)
+                 for sx in [stream] + [x.cuda_stream for x in xs]]
+        p = Pipeline(calls, {})
+
+        def f():
+            p.submit(False)
+        f.drain = p.drain
+        f.keepalive = xs
+        return f
+    step.overlapped = overlapped
 
     def sync_call_ms(reps=30):
         """The same call made synchronously (what a caller that needs the row counts before its next step pays)."""
@@ -361,7 +409,7 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     step.sync_call_ms = sync_call_ms
 
     step.rank_step = rank_step
-    step.keepalive = (d_data, d_off)
+    step.keepalive = (d_data, d_off, extra)
     step()
     first = step.drain()[0]      # also fills output_bytes
     assert first["records"] == n
@@ -463,20 +511,23 @@ def encode_main(args):
                        "stage_ms": {key: round(float(hst[key]), 3) for key in ("h2d_ms", "size_kernel_ms", "scan_kernel_ms", "emit_kernel_ms", "d2h_ms", "total_ms")}}}))
 
 
-def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int = 40):
+def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int = 40, overlapped_1gpu=None):
     """BASELINE config 5 without an 8-GPU node: the step ONE rank would run when the same list is dealt to g GPUs
     (rank 0's chunks of it, the list's chunk geometry via rh_opts.chunk_rows), timed on this GPU like the main loop
-    (calls back to back, one sync at the end).  Ranks are independent (no data-path collective), so the job's step
-    at g GPUs is the slowest rank's step: implied strong-scaling efficiency = (ms_per_step at 1 GPU / g) / that.
-    A PROJECTION from one GPU -- the RCCL barrier and the MAX over ranks of the real run are not in it."""
+    (asynchronous calls, settled PIPELINE_DEPTH steps later, one sync at the end).  Ranks are independent (no data-path
+    collective), so the job's step at g GPUs is the slowest rank's step: implied strong-scaling efficiency =
+    (ms_per_step at 1 GPU / g) / that.  A PROJECTION from one GPU -- the RCCL barrier and the MAX over ranks of the
+    real run are not in it.  `overlapped`: the same with the steps dealt to OVERLAP_STREAMS streams, against the
+    1-GPU figure measured the same way."""
     import torch
     out = {"what": "per-rank step of the 10M-record list over g GPUs, measured on this one GPU; a projection, not an N-GPU run",
            "ms_per_step_1gpu": ms_per_step_1gpu, "g": {}}
-    for g in (2, 4, 8):
-        if g > num_chunks:
-            continue
-        f, sh = step.rank_step(g)
-        for _ in range(5):
+    if overlapped_1gpu:
+        out["overlapped_streams"] = overlapped_1gpu["streams"]
+        out["overlapped_ms_per_step_1gpu"] = overlapped_1gpu["ms_per_step"]
+
+    def timed(f):
+        for _ in range(6):
             f()
         f.drain()
         torch.cuda.synchronize()
@@ -485,10 +536,23 @@ def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int
             f()
         f.drain()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) * 1e3 / reps
-        out["g"][str(g)] = {"records_per_rank": sh["rows"], "chunks_per_rank": sh["chunks"], "ms_per_step": ms,
-                            "ideal_ms": ms_per_step_1gpu / g, "implied_efficiency": (ms_per_step_1gpu / g) / ms if ms > 0 else 0.0,
-                            "implied_records_per_s": sh["rows"] * g / (ms * 1e-3) if ms > 0 else 0.0}
+        return (time.perf_counter() - t) * 1e3 / reps
+
+    for g in (2, 4, 8):
+        if g > num_chunks:
+            continue
+        f, sh = step.rank_step(g)
+        ms = timed(f)
+        e = {"records_per_rank": sh["rows"], "chunks_per_rank": sh["chunks"], "ms_per_step": ms,
+             "ideal_ms": ms_per_step_1gpu / g, "implied_efficiency": (ms_per_step_1gpu / g) / ms if ms > 0 else 0.0,
+             "implied_records_per_s": sh["rows"] * g / (ms * 1e-3) if ms > 0 else 0.0}
+        if overlapped_1gpu:
+            f2, _ = step.rank_step(g, 0, overlapped_1gpu["streams"])
+            ms2 = timed(f2)
+            base = overlapped_1gpu["ms_per_step"]
+            e["overlapped"] = {"ms_per_step": ms2, "ideal_ms": base / g, "implied_efficiency": (base / g) / ms2 if ms2 > 0 else 0.0,
+                               "implied_records_per_s": sh["rows"] * g / (ms2 * 1e-3) if ms2 > 0 else 0.0}
+        out["g"][str(g)] = e
     return out
 
 
@@ -496,9 +560,11 @@ def main(argv=None):
     args = parse_args(argv)
     if args.direction == "encode":
         return encode_main(args)
-    global KERNEL, SYNC_CALLS
+    global KERNEL, SYNC_CALLS, STREAMS, OVERLAP_STREAMS
     KERNEL = {"auto": 0, "generic": 1, "specialized": 2}[args.kernel]
     SYNC_CALLS = bool(args.sync_calls)
+    STREAMS = max(1, int(args.streams))
+    OVERLAP_STREAMS = int(args.overlap_streams)
     import torch  # noqa: F401  (first: our library must share torch's HIP runtime)
     from avrogen.schemas import SCHEMAS
 
@@ -584,14 +650,26 @@ def main(argv=None):
                    "kernel_form": "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter",
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
                    "calls": ("synchronous: every step waits for its own call" if SYNC_CALLS else
-                             f"RH_ASYNC, settled {PIPELINE_DEPTH} steps later (rh_device_result_wait), everything inside the timed region"),
+                             f"RH_ASYNC on {STREAMS} stream(s), settled {PIPELINE_DEPTH} steps later (rh_device_result_wait), everything inside the timed region"),
                    "sync_call_ms": run.step.sync_call_ms() if hasattr(run.step, "sync_call_ms") else None,
                    "path_kernel_ms": path_ms,
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": roofline,
     }
+    if getattr(run, "overlapped", None):
+        ov = run.overlapped
+        total = sum(r["records"] for r in per_rank) * args.steps
+        out["overlapped"] = {
+            "what": (f"the same {args.steps} steps dealt round-robin to {ov['streams']} HIP streams (independent batches: one step's size pass "
+                     "runs beside another's emit pass); second timed region, same barriers; not the headline because kernels that "
+                     "share the chip have no per-kernel duration to price against the roofline"),
+            "streams": ov["streams"], "ms_per_step": ov["ms_per_step"], "value": total / ov["wall_s"] if ov["wall_s"] > 0 else 0.0,
+            "unit": "records/s",
+            "path_alg_GBps": alg_bytes / (ov["ms_per_step"] * 1e-3) / 1e9 if ov["ms_per_step"] > 0 and world == 1 else None,
+            "path_frac": alg_bytes / (ov["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if ov["ms_per_step"] > 0 and world == 1 else None}
     if world == 1 and shard_whole and hasattr(run.step, "rank_step") and not args.no_projection:
-        out["config5_projection"] = config5_projection(run.step, wall * 1e3 / args.steps, num_chunks)
+        out["config5_projection"] = config5_projection(run.step, wall * 1e3 / args.steps, num_chunks,
+                                                       overlapped_1gpu=getattr(run, "overlapped", None))
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n) if args.cpu_sample else n, num_chunks)
     if not args.no_end_to_end and world == 1:

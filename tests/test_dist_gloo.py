@@ -56,7 +56,7 @@ REAL_WORKER = textwrap.dedent("""
         data, offsets = fastgen.generate(gen_cfg, N)
         exp = c_walker.decode_packed(c_walker.CompiledSchema(SCHEMAS[gen_cfg]), data, offsets, K, threaded=True)
         mine = exp[shard["chunk_lo"]: shard["chunk_hi"]]
-        d_data, d_off = step.keepalive
+        d_data, d_off = step.keepalive[:2]
         r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), info["input_bytes"], shard["rows"], SCHEMAS[gen_cfg],
                                shard["chunks"], device=0, chunk_rows=shard["chunk_rows"])
         got = r.to_host()
