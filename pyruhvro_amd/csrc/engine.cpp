@@ -1868,6 +1868,63 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
 // ===========================================================================
 // C ABI
 // ===========================================================================
+// RUHVRO_HIP_STATS=1: one JSON line per host decode call on stderr (the reference has no metrics
+// at all; this is the per-call stats struct of the C ABI, printed) -- entry point, records, bytes, per-stage ms, per-shard
+// when the call was dealt to several devices.
+bool stats_line_on() {
+  static const bool on = [] { const char* e = std::getenv("RUHVRO_HIP_STATS"); return e && *e && *e != '0'; }();
+  return on;
+}
+void stats_json(std::string& o, const rh_stats& st) {
+  char buf[512];
+  std::snprintf(buf, sizeof buf,
+                "{\"records\": %llu, \"input_bytes\": %llu, \"output_bytes\": %llu, \"chunks\": %u, \"blocks\": %u, \"pack_ms\": %.4f, "
+                "\"h2d_ms\": %.4f, \"size_kernel_ms\": %.4f, \"scan_kernel_ms\": %.4f, \"emit_kernel_ms\": %.4f, \"d2h_ms\": %.4f, "
+                "\"total_ms\": %.4f, \"specialized\": %u, \"lds_bytes\": %u}",
+                (unsigned long long)st.records, (unsigned long long)st.input_bytes, (unsigned long long)st.output_bytes, st.chunks,
+                st.blocks, st.pack_ms, st.h2d_ms, st.size_kernel_ms, st.scan_kernel_ms, st.emit_kernel_ms, st.d2h_ms, st.total_ms,
+                st.specialized, st.lds_bytes);
+  o += buf;
+}
+void stats_line(const char* entry, int rc, const rh_stats& st, const rh_opts* opts, const rh_stats* shards) {
+  std::string o = "{\"ruhvro_hip\": \"";
+  o += entry;
+  o += "\", \"rc\": " + std::to_string(rc) + ", \"stats\": ";
+  stats_json(o, st);
+  if (shards && opts && opts->n_devices > 1) {
+    o += ", \"devices\": [";
+    for (uint32_t i = 0; i < opts->n_devices; i++) {
+      if (i) o += ", ";
+      o += "{\"device\": " + std::to_string(opts->devices[i]) + ", \"stats\": ";
+      stats_json(o, shards[i]);
+      o += "}";
+    }
+    o += "]";
+  }
+  o += "}\n";
+  std::fputs(o.c_str(), stderr);
+}
+// runs a host decode entry point with the stats struct forced on when the line was asked for
+template <class F>
+int with_stats_line(const char* entry, const rh_opts* opts, rh_stats* stats, F&& f) {
+  if (!stats_line_on()) return f(opts, stats);
+  rh_stats local;
+  std::memset(&local, 0, sizeof local);
+  rh_stats* st = stats ? stats : &local;
+  std::vector<rh_stats> shard_st;
+  rh_opts o2;
+  const rh_opts* use = opts;
+  if (opts && opts->n_devices > 1 && !opts->device_stats) {       // per-shard timings for the line
+    shard_st.resize(opts->n_devices);
+    o2 = *opts;
+    o2.device_stats = shard_st.data();
+    use = &o2;
+  }
+  const int rc = f(use, st);
+  stats_line(entry, rc, *st, use, use ? use->device_stats : nullptr);
+  return rc;
+}
+
 extern "C" {
 
 int rh_abi_version(void) { return RH_ABI_VERSION; }
@@ -2045,22 +2102,26 @@ void rh_device_result_free(rh_device_result* r) { delete r; }
 int rh_decode_packed(const rh_schema* s, const uint8_t* data, const uint64_t* offsets, uint64_t n, uint64_t num_chunks,
                      const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !offsets || !out_chunks) return RH_ERR_ARGUMENT;
-  return guarded(err, [&] {
-    Source src;
-    src.data = data;
-    src.offsets = offsets;
-    return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, opts, out_chunks, out_k, stats);
+  return with_stats_line("rh_decode_packed", opts, stats, [&](const rh_opts* o, rh_stats* st) {
+    return guarded(err, [&] {
+      Source src;
+      src.data = data;
+      src.offsets = offsets;
+      return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, o, out_chunks, out_k, st);
+    });
   });
 }
 
 int rh_decode(const rh_schema* s, const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint64_t num_chunks,
               const rh_opts* opts, struct ArrowArray* out_chunks, uint32_t* out_k, rh_stats* stats, char** err) {
   if (!s || !out_chunks || (n && (!ptrs || !lens))) return RH_ERR_ARGUMENT;
-  return guarded(err, [&] {
-    Source src;          // the record slices are gathered per shard, inside decode_range
-    src.ptrs = ptrs;
-    src.lens = lens;
-    return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, opts, out_chunks, out_k, stats);
+  return with_stats_line("rh_decode", opts, stats, [&](const rh_opts* o, rh_stats* st) {
+    return guarded(err, [&] {
+      Source src;          // the record slices are gathered per shard, inside decode_range
+      src.ptrs = ptrs;
+      src.lens = lens;
+      return decode_host_impl(const_cast<rh_schema*>(s), src, n, num_chunks, o, out_chunks, out_k, st);
+    });
   });
 }
 

@@ -17,7 +17,7 @@ import json
 import struct
 from typing import List, Tuple
 
-from avrogen.encoder import Blocks, Branch, to_datum, zigzag
+from avrogen.encoder import Blocks, Branch, Unscaled, to_datum, zigzag
 from avrogen.schemas import SCHEMAS
 from oracle.avro_schema import parse_schema
 
@@ -301,3 +301,62 @@ def long_string_case(n=1500, seed=5):
                      "ll": [[st() for _ in range(r.choice([0, 1, 3]))] for _ in range(r.choice([0, 1, 2]))],
                      "z": st()})
     return s, _enc(s, vals)
+
+
+def dense_list_cases():
+    """Top-level arrays / maps in the shapes the specialised emit kernel handles one lane per ITEM (spec_body.h
+    dense_list): every body kind, more items per wavefront than its position table holds (several rounds), one huge list
+    among short ones, positive multi-block lists, two-byte block counts, nullable lists, N4 leaves in list items.  All
+    records take the fast wire forms, so the tiles stay on the trusted fast walk.  -> list of (name, schema_json, records)."""
+    out = []
+    s = json.dumps({"type": "record", "name": "DL1", "fields": [
+        {"name": "id", "type": "long"}, {"name": "tags", "type": {"type": "array", "items": "string"}},
+        {"name": "m", "type": {"type": "map", "values": "string"}}, {"name": "tail", "type": ["null", "int"]}]})
+    vals = [{"id": i, "tags": [f"t{i}-{j}" * (1 + (i + j) % 4) for j in range(10 + i % 31)],
+             "m": [(f"k{j}", "v" * ((i * j) % 23)) for j in range(i % 7)], "tail": None if i % 3 else i} for i in range(600)]
+    out.append(("dense_long_lists", s, _enc(s, vals)))
+    vals = [{"id": i, "tags": [f"x{j}" for j in range(700 if i % 97 == 5 else i % 3)],
+             "m": [(f"key{i}{j}", f"value-{j}") for j in range(300 if i % 131 == 7 else i % 2)], "tail": i} for i in range(700)]
+    out.append(("dense_skewed", s, _enc(s, vals)))
+    vals = []
+    for i in range(520):
+        items = [f"it{i}.{j}" for j in range(i % 9)]
+        blocks = [(items[b:b + 2 + i % 2], False) for b in range(0, len(items), 2 + i % 2)]        # positive counts only
+        pairs = [(f"k{j}", f"{i}:{j}") for j in range(i % 5)]
+        vals.append({"id": -i, "tags": Blocks(blocks), "m": Blocks([(pairs[b:b + 1], False) for b in range(len(pairs))]),
+                     "tail": None})
+    out.append(("dense_multiblock_positive", s, _enc(s, vals)))
+    vals = [{"id": i, "tags": ["q" * (j % 5) for j in range(64 + i % 120)], "m": [(f"{j}", "") for j in range(70)], "tail": 1}
+            for i in range(300)]
+    out.append(("dense_two_byte_counts", s, _enc(s, vals)))
+    s2 = json.dumps({"type": "record", "name": "DL2", "fields": [
+        {"name": "rs", "type": {"type": "array", "items": {"type": "record", "name": "It", "fields": [
+            {"name": "a", "type": "int"}, {"name": "s", "type": ["null", "string"]},
+            {"name": "e", "type": {"type": "enum", "name": "DE", "symbols": ["red", "green", "b"]}},
+            {"name": "u", "type": ["null", "long", "string", "boolean"]}, {"name": "d", "type": "double"},
+            {"name": "nb", "type": ["null", "boolean"]}]}}},
+        {"name": "mr", "type": {"type": "map", "values": ["null", {"type": "record", "name": "Mv", "fields": [
+            {"name": "x", "type": "float"}, {"name": "t", "type": "string"}]}]}},
+        {"name": "es", "type": {"type": "array", "items": {"type": "enum", "name": "DE2", "symbols": ["A", "BB", "CCC"]}}},
+        {"name": "ni", "type": {"type": "array", "items": ["null", "int"]}},
+        {"name": "after", "type": "string"}]})
+    vals = []
+    for i in range(560):
+        rs = [{"a": i * j, "s": None if (i + j) % 3 == 0 else f"s{i}/{j}", "e": ["red", "green", "b"][(i + j) % 3],
+               "u": [None, i * 1000 + j, f"u{j}", j % 2 == 0][(i + j) % 4], "d": i / (j + 1), "nb": [None, True, False][(i * j) % 3]}
+              for j in range(i % 6)]
+        mr = [(f"m{j}", None if (i + j) % 4 == 0 else {"x": float(j), "t": "t" * (j % 9)}) for j in range(i % 4)]
+        vals.append({"rs": rs, "mr": mr, "es": ["A", "BB", "CCC"][: i % 4] * (1 + i % 3), "ni": [None if j % 2 else j for j in range(i % 8)],
+                     "after": f"after{i}"})
+    out.append(("dense_record_items", s2, _enc(s2, vals)))
+    s3 = json.dumps({"type": "record", "name": "DL3", "fields": [
+        {"name": "na", "type": ["null", {"type": "array", "items": "string"}]},
+        {"name": "an", "type": [{"type": "array", "items": "long"}, "null"]},
+        {"name": "fx", "type": {"type": "array", "items": {"type": "fixed", "name": "F4", "size": 4}}},
+        {"name": "dm", "type": {"type": "map", "values": {"type": "bytes", "logicalType": "decimal", "precision": 12, "scale": 2}}},
+        {"name": "k", "type": "int"}]})
+    vals = [{"na": None if i % 4 == 0 else [f"n{j}" for j in range(i % 5)], "an": None if i % 3 == 1 else [i * j for j in range(i % 6)],
+             "fx": [bytes([i % 256, j, 3, 4]) for j in range(i % 4)], "dm": [(f"d{j}", Unscaled((-1) ** j * (i * 37 + j))) for j in range(i % 3)],
+             "k": i} for i in range(530)]
+    out.append(("dense_nullable_and_n4", s3, _enc(s3, vals)))
+    return out

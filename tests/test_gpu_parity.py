@@ -96,6 +96,30 @@ def test_wire_forms_and_nesting(case):
     _check((recs * 40)[:1000], schema, 7)
 
 
+@pytest.mark.parametrize("case", cases.dense_list_cases(), ids=lambda c: c[0])
+def test_item_dense_lists(case):
+    """The specialised emit kernel materialises top-level arrays / maps one lane per ITEM (spec_body.h dense_list):
+    every body kind, wavefronts with more items than the position table holds (rounds), one huge list among short ones,
+    positive multi-block lists, two-byte block counts, nullable lists, N4 leaves -- buffer for buffer against the oracle,
+    on both kernel forms (the generic interpreter keeps the per-record loop: the two must agree with each other too)."""
+    name, schema, recs = case
+    if "n4" in name:       # types beyond the reference's direct path: the specification oracle (py_walker, extended)
+        from oracle import py_walker
+        exp = py_walker.decode(recs, schema, extended=True)
+        for k in (1, 4):
+            got = P.deserialize_array_threaded(recs, schema, k)
+            assert sum(b.num_rows for b in got) == exp.num_rows
+            off = 0
+            for g in got:
+                g.validate(full=True)
+                assert_batches_identical(g, py_walker.decode(recs[off: off + g.num_rows], schema, extended=True))
+                off += g.num_rows
+        return
+    for k in (1, 3, 8):
+        _check(recs, schema, k)
+    _check((recs * 3)[7:], schema, 5)          # other tile / wave positions for every row
+
+
 @pytest.mark.parametrize("case", cases.error_cases(), ids=lambda c: c[0])
 def test_error_messages_match_reference(case):
     _, schema, good, bad, msg = case
@@ -335,3 +359,28 @@ def test_any_lds_window_size(pct, pad, monkeypatch):
     monkeypatch.setenv("RUHVRO_HIP_WIN_PAD", str(pad))
     for name, n, k in (("full", 5003, 7), ("cfg3", 3000, 2), ("array_and_map", 2500, 3)):
         _check(synth.records(name, n, seed=3), SCHEMAS[name], k)
+
+
+def test_stats_json_line(tmp_path):
+    """RUHVRO_HIP_STATS=1: one JSON line per host decode call on stderr (the per-call stats struct of the C ABI, with the
+    per-shard entries of a call dealt to several devices) -- SURVEY.md section 5's metrics row."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import torch; import pyruhvro_amd as P\n"
+            "from avrogen import synth; from avrogen.schemas import SCHEMAS\n"
+            "recs = synth.records('full', 3000)\n"
+            "P.deserialize_array_threaded(recs, SCHEMAS['full'], 4)\n"
+            "P.set_devices([0, 0]); P.deserialize_array_threaded(recs, SCHEMAS['full'], 4)\n"
+            "try:\n    P.deserialize_array_threaded(recs[:10] + [b'\\x80'], SCHEMAS['full'], 2)\nexcept ValueError:\n    pass\n"
+            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RUHVRO_HIP_STATS="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = [json.loads(l) for l in p.stderr.splitlines() if l.startswith('{"ruhvro_hip"')]
+    assert len(lines) == 3, p.stderr
+    a, b, c = lines
+    assert a["ruhvro_hip"] == "rh_decode" and a["rc"] == 0 and a["stats"]["records"] == 3000 and a["stats"]["chunks"] == 4
+    assert a["stats"]["emit_kernel_ms"] > 0 and a["stats"]["total_ms"] >= a["stats"]["emit_kernel_ms"] and a["stats"]["output_bytes"] > 0
+    assert [d["device"] for d in b["devices"]] == [0, 0] and sum(d["stats"]["records"] for d in b["devices"]) == 3000
+    assert c["rc"] == 2                                       # RH_ERR_DECODE: the line is printed for failed calls too
