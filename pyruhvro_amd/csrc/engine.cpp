@@ -1027,7 +1027,7 @@ struct rh_decode_call {
 
     // LDS: fixed part + input window sized from the mean record length (falls back to global reads
     // for workgroups whose 256 records do not fit)
-    const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
+    const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs), rh::dom0_bitmap_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
     payload = geo ? geo->payload_bytes : data_len;
     const uint64_t avg = n ? payload / n + 1 : 16;
     // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD)

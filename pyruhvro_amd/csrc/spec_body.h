@@ -99,8 +99,13 @@ struct SCtx {
   // domain-0 bitmaps: rows == lanes, one ballot and one 64-bit store per wavefront and field.  (Collecting the ~15 words
   // of a wave in one VGPR with v_writelane and storing them once was measured: no gain, profiles/r02g_variants_ab.txt.)
   __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
-    if (lane == 0 && wave_live) st_global<uint64_t, kWide>(this->buf(buf), lrow >> 6, m);
+    // the tile's domain-0 bitmap words are collected in LDS and stored by ONE instruction per workgroup (spec_emit tail)
+    // instead of one single-lane store per field and wave: a store costs the vector-memory path ~16 cycles even with one
+    // active lane (tools/storecost.hip), 11-14 such words per wave on the benchmark schema (k_emit -4.2 %,
+    // profiles/r03y_variants_ab.txt; the per-WAVE collection of round 2 -- v_writelane, one store per wave -- had not paid)
+    if (lane == 0) bmw0[S::bm0slot(buf) * (S::TILE / 64) + (lrow & (S::TILE - 1)) / 64] = m;
   }
+  uint64_t* bmw0;                                     // LDS [NB0][NW]: this tile's domain-0 bitmap words
   uint32_t* bm;                                       // LDS [NBM][kBmWords]
   __device__ __forceinline__ void set_bit(int buf, int dom, uint32_t row) const {
     if constexpr (S::NBM > 0) {
@@ -146,10 +151,10 @@ __device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[
 }
 
 // LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
-// a dense list)   (host mirror: spec_lds_fixed_words_host)
-__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense) {
+// a dense list) | bmw0[NB0][NW] u64   (host mirror: spec_lds_fixed_words_host)
+__host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
   return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
-         (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u);
+         (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
 }
 
 // Tile geometry of a specialised kernel: S::TILE records = S::TILE threads = NW wavefronts per workgroup.
@@ -167,6 +172,7 @@ struct SpecSmem {
   uint32_t* misc;
   uint32_t* bm;
   uint32_t* dtab;
+  uint64_t* bmw0;
   uint8_t* win;
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
@@ -175,6 +181,7 @@ struct SpecSmem {
     misc = p; p += 4;
     bm = p; p += S::NBM * kBmWords;                   // a multiple of 16 bytes
     dtab = p; p += S::NDENSE > 0 ? (S::TILE / 64) * kDenseCap : 0;
+    bmw0 = reinterpret_cast<uint64_t*>(p); p += (S::NB0 * (S::TILE / 64) * 2 + 3) & ~3;   // (8-byte aligned: every part is a multiple of 16 bytes)
     win = reinterpret_cast<uint8_t*>(p);
   }
 };
@@ -286,6 +293,7 @@ __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, cons
   c.nullcnt = s.nullcnt; c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
   c.dtab = s.dtab + (tid >> 6) * kDenseCap; c.wtot_w = s.wtot + (tid >> 6);
+  c.bmw0 = s.bmw0;
 }
 
 // --------------------------------------------------------------------------
@@ -447,6 +455,12 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   for (int i = tid; i < S::NNODES; i += T) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
+  }
+  if constexpr (S::NB0 > 0) {   // the tile's domain-0 bitmap words (SCtx::put_word0): one lane per word
+    for (uint32_t i = tid; i < (uint32_t)(S::NB0 * NW); i += T) {
+      const uint32_t slot = i / NW, w = i % NW;
+      if (w * 64u < g.nrec) st_global<uint64_t, false>(c.buf(S::bm0buf(slot)), (g.lrow0 >> 6) + w, c.bmw0[i]);
+    }
   }
   if constexpr (S::NBM > 0) {   // the tile's child-domain bitmap words: one atomicOr per non-zero word (the first and
     static_for<0, S::NBM>([&](auto ib) {   // the last word of a run are shared with the neighbouring tiles)

@@ -24,9 +24,15 @@ std::vector<char> compile_kernel(const std::string& source, std::string& log);
 std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache, bool encode = false);
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
-inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw, int nbm, int ndense) {
+inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
   return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * 64) +
-         (ndense > 0 ? (uint32_t)(nw * 128) : 0u);
+         (ndense > 0 ? (uint32_t)(nw * 128) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
+}
+// domain-0 bitmap buffers of a schema (their words are collected per tile in LDS by the specialised emit kernel)
+inline int dom0_bitmap_count(const CompiledSchema& cs) {
+  int n = 0;
+  for (const BufDesc& d : cs.bufs) n += (d.kind == BK_BITMAP && d.dom == 0) ? 1 : 0;
+  return n;
 }
 // Lists the specialised emit kernel handles one lane per ITEM (spec_body.h dense_list): top-level arrays / maps without
 // nested lists.  0 when RUHVRO_HIP_NO_DENSE=1 (A/B knob, read once: it changes the generated source and its LDS layout).
