@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_WRITE_TAGCONFLICT_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_TOTAL_ACCESSES TCP_TCC_READ_REQ" \
            "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-projection > $OUT/p$i.log 2>&1; echo "pass $i rc=$?"
+  timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p$i -- python bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-projection --overlap-streams 0 > $OUT/p$i.log 2>&1; echo "pass $i rc=$?"
   for f in $(find $OUT/p$i -name "*.db"); do python scripts/rocpd_summary.py $f 2>&1 | grep -E "^(rh_|kernel)" > $OUT/p$i.txt; done
   rm -rf $OUT/p$i
 done

@@ -5,7 +5,7 @@ TAG=${1:-prof_r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="--no-cpu-baseline --no-end-to-end --no-projection"
+B="--no-cpu-baseline --no-end-to-end --no-projection --overlap-streams 0"   # profiler passes: single-stream launches only (kernels that share the chip have inflated durations by design)
 summ() { for f in $(find $1 -name "*.db"); do python scripts/rocpd_summary.py $f; done; }
 # A. the default bench line (what the driver runs)
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
