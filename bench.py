@@ -5,10 +5,16 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (k_size -> k_scan -> k_emit, C ABI rh_decode_device) over one batch of
-synthetic Avro records that is ALREADY resident in HBM; the Arrow buffers are produced in HBM.  Workload
+A step = one pass of the hot path (k_size -> k_scan+layout -> k_emit -> k_publish, C ABI rh_decode_device) over one batch
+of synthetic Avro records that is ALREADY resident in HBM; the Arrow buffers are produced in HBM.  Workload
 (BASELINE.json config 4, the one the metric's target is quoted on): 10,000,000 records of the
 scripts/generate_avro.py schema, num_chunks = 8.
+
+The K timed steps are made with RH_ASYNC (ABI 4): each call returns once it is on the stream and is settled
+(rh_device_result_wait: error check, row / null counts) and freed PIPELINE_DEPTH steps later, so the host's turn-around
+overlaps the next step; every step's kernels, control-word publish and settle are inside the timed region, which is
+closed by draining the pipeline + the barrier + torch.cuda.synchronize().  `config.sync_call_ms` is the same call made
+synchronously.  The arenas / workspaces the in-flight calls own are taken from the allocator (and touched) in set-up.
 
 N > 1 (BASELINE.json config 5): the SAME seeded 10M-record list, its 8 reference chunks
 (ruhvro/src/deserialize.rs:57-68) dealt to the ranks in contiguous runs (rh_shard_chunks: rank r of N decodes chunks
@@ -22,8 +28,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                 path against the same bytes (`path_frac`), the north star's own figure -- HBM READ bandwidth of the two
                 passes together, rocprofv3 FETCH_SIZE of both (stamped file) / their time (`read_GBps`, `read_frac`) --
                 and one sub-object per kernel (`kernels`).
+  overlapped    a SECOND timed region: the same K steps dealt round-robin to --overlap-streams (3) HIP streams.  Independent
+                batches overlap well (the size pass is VALU-bound, the emit pass store-path-bound), but kernels that share
+                the chip have no per-kernel duration to price against the roofline, so this is reported beside `value`,
+                never as it.  (Profiler passes run with --overlap-streams 0: their per-kernel averages are those of the
+                single-stream region the `roofline` object describes.)
   config5_projection  (N=1) the step ONE rank of BASELINE config 5 would run when the list is dealt to 2 / 4 / 8 GPUs,
-                measured on this GPU, and the strong-scaling efficiency it implies.  A projection, labelled as one.
+                measured on this GPU, and the strong-scaling efficiency it implies, single-stream and overlapped.
+                A projection, labelled as one.
   cpu_baseline  the oracle's C restatement of the reference walker ("port"), reference threading shape
                 (serial pack + one thread per chunk), timed on this box's host cores on the SAME records, best of 5:
                 with the workload's 8 chunks = 8 threads, and (`wide`) with min(64, cores) chunks.  Reported, not targeted.
