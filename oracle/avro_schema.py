@@ -85,8 +85,13 @@ def _split_name(name: str, explicit_ns: Optional[str], enclosing_ns: Optional[st
 
 
 class _Parser:
-    def __init__(self) -> None:
+    def __init__(self, resolve_refs: bool = False) -> None:
         self.named: Dict[str, str] = {}
+        # resolve_refs (beyond the reference, which stops at Schema::Ref): a reference to a named type IS that type
+        # (Avro specification) -- substitute a copy of its completed definition; a reference to a type that is still
+        # being defined is a recursive type, which no Arrow schema can express
+        self.resolve_refs = resolve_refs
+        self.defs: Dict[str, AvroSchema] = {}
 
     def parse(self, j, enclosing_ns: Optional[str]) -> AvroSchema:
         if isinstance(j, str):
@@ -103,6 +108,11 @@ class _Parser:
         simple, ns = _split_name(s, None, enclosing_ns)
         full = f"{ns}.{simple}" if ns else simple
         if full in self.named:
+            if self.resolve_refs:
+                if full not in self.defs:
+                    raise SchemaError(f"recursive named type {full}: a type that contains itself has no Arrow schema")
+                import copy
+                return copy.deepcopy(self.defs[full])
             # apache-avro turns a repeated named type into Schema::Ref, which
             # neither is_supported (fast_decode.rs:59) nor schema_translate
             # (schema_translate.rs:51, todo!()) handles.
@@ -166,8 +176,10 @@ class _Parser:
                 sz = d.get("size")
                 if not isinstance(sz, int) or isinstance(sz, bool) or sz < 0:
                     raise SchemaError("No `size` in fixed")
-                return AvroSchema(kind="fixed", name=simple, namespace=ns, size=sz,
-                                  doc=d.get("doc"), aliases=d.get("aliases"))
+                fx = AvroSchema(kind="fixed", name=simple, namespace=ns, size=sz,
+                                doc=d.get("doc"), aliases=d.get("aliases"))
+                self.defs[fx.fullname()] = fx
+                return fx
             return self._parse_name(t, enclosing_ns)
         if isinstance(t, dict):
             return self._parse_complex(t, enclosing_ns)
@@ -202,9 +214,11 @@ class _Parser:
             seen.add(f["name"])
             fields.append(AvroField(name=f["name"], schema=self.parse(f["type"], ns),
                                     doc=f.get("doc") if isinstance(f.get("doc"), str) else None))
-        return AvroSchema(kind="record", name=simple, namespace=ns, fields=fields,
-                          doc=d.get("doc") if isinstance(d.get("doc"), str) else None,
-                          aliases=d.get("aliases") if isinstance(d.get("aliases"), list) else None)
+        rec = AvroSchema(kind="record", name=simple, namespace=ns, fields=fields,
+                         doc=d.get("doc") if isinstance(d.get("doc"), str) else None,
+                         aliases=d.get("aliases") if isinstance(d.get("aliases"), list) else None)
+        self.defs[rec.fullname()] = rec
+        return rec
 
     def _parse_enum(self, d: dict, enclosing_ns: Optional[str]) -> AvroSchema:
         simple, ns = self._register(d, enclosing_ns)
@@ -213,9 +227,11 @@ class _Parser:
             raise SchemaError("No `symbols` field in enum")
         if len(set(syms)) != len(syms):
             raise SchemaError("Duplicate enum symbol")
-        return AvroSchema(kind="enum", name=simple, namespace=ns, symbols=list(syms),
-                          doc=d.get("doc") if isinstance(d.get("doc"), str) else None,
-                          aliases=d.get("aliases") if isinstance(d.get("aliases"), list) else None)
+        en = AvroSchema(kind="enum", name=simple, namespace=ns, symbols=list(syms),
+                        doc=d.get("doc") if isinstance(d.get("doc"), str) else None,
+                        aliases=d.get("aliases") if isinstance(d.get("aliases"), list) else None)
+        self.defs[en.fullname()] = en
+        return en
 
 
 _LOGICAL_BASE = {
@@ -234,13 +250,14 @@ _LOGICAL_BASE = {
 }
 
 
-def parse_schema(schema_json: str) -> AvroSchema:
-    """deserialize.rs:18-20 -> apache_avro::Schema::parse_str."""
+def parse_schema(schema_json: str, resolve_refs: bool = False) -> AvroSchema:
+    """deserialize.rs:18-20 -> apache_avro::Schema::parse_str.  resolve_refs: named-type references are replaced by the
+    definition they name (the engine's behaviour, beyond the reference: schema_translate.rs:51 is a todo!())."""
     try:
         j = json.loads(schema_json)
     except json.JSONDecodeError as e:
         raise SchemaError(f"Failed to parse schema from JSON: {e}") from None
-    return _Parser().parse(j, None)
+    return _Parser(resolve_refs).parse(j, None)
 
 
 # ---------------------------------------------------------------------------

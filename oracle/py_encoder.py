@@ -313,7 +313,7 @@ def serialize_chunk(schema: S.AvroSchema, sa: pa.Array) -> pa.Array:
 
 def serialize_record_batch(rb: pa.RecordBatch, schema_json: str, num_chunks: int, extended: bool = False) -> List[pa.Array]:
     """serialize.rs:38-67: k = clamp(num_chunks, 1, max(rows, 1)); chunk i = rows [i*sz, (i+1)*sz), last takes the rest."""
-    s = S.parse_schema(schema_json)
+    s = S.parse_schema(schema_json, resolve_refs=extended)
     if not (S.is_supported_extended(s) if extended else S.is_supported(s)):
         raise EncodeError("schema is outside the fast encode path (fast_encode::is_supported == false)")
     sa = rb.to_struct_array()

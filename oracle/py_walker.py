@@ -327,7 +327,7 @@ class _B:
 def decode(records: List[bytes], schema_json: str, extended: bool = False):
     """fast_decode::decode (fast_decode.rs:806-835) -> pyarrow.RecordBatch.  ``extended``: also the N4 leaf types the
     reference's gate rejects (avro_schema.is_supported_extended)."""
-    avro = S.parse_schema(schema_json)
+    avro = S.parse_schema(schema_json, resolve_refs=extended)
     arrow_schema, root = S.build_tree(avro, extended)
     top = _B(root)
     for rec in records:

@@ -15,8 +15,31 @@ using json::Value;
 // ===========================================================================
 // 1. Avro schema JSON -> type tree  (apache_avro::Schema::parse_str subset)
 // ===========================================================================
+// deep copy of a type tree (a named-type reference becomes a copy of the definition it names)
+std::unique_ptr<AvroType> clone_type(const AvroType& t) {
+  auto c = std::make_unique<AvroType>();
+  c->kind = t.kind; c->name = t.name; c->ns = t.ns; c->has_doc = t.has_doc; c->doc = t.doc;
+  c->has_aliases = t.has_aliases; c->aliases = t.aliases; c->symbols = t.symbols; c->logical = t.logical;
+  c->size = t.size; c->precision = t.precision; c->scale = t.scale;
+  for (const AvroField& f : t.fields) {
+    AvroField g;
+    g.name = f.name; g.has_doc = f.has_doc; g.doc = f.doc;
+    g.type = clone_type(*f.type);
+    c->fields.push_back(std::move(g));
+  }
+  if (t.items) c->items = clone_type(*t.items);
+  for (const auto& v : t.variants) c->variants.push_back(clone_type(*v));
+  return c;
+}
+
 struct Parser {
   std::set<std::string> named;
+  // completed definitions of the named types seen so far.  The reference stops at a named-type reference
+  // (schema_translate.rs:51 `todo!("Add support for AvroSchema::Ref")`, gated out at fast_decode.rs:59); here a
+  // reference is resolved the way the Avro specification defines it -- it IS the type it names -- by substituting a
+  // copy of the definition, so everything downstream (gate, Arrow translation, decoder tree) sees an ordinary tree.
+  // A reference to a type that is still being defined is a recursive type: no Arrow schema can express it.
+  std::map<std::string, std::unique_ptr<AvroType>> defs;   // (copies: a logical type may replace the node it wraps)
 
   static void split_name(const std::string& raw, const Value* ns_attr, const std::string& enclosing,
                          std::string& simple, std::string& ns) {
@@ -56,10 +79,10 @@ struct Parser {
     split_name(s, nullptr, enclosing, simple, ns);
     std::string full = ns.empty() ? simple : ns + "." + simple;
     if (named.count(full)) {
-      auto t = prim(AV_REF);   // apache-avro: Schema::Ref (unsupported downstream, fast_decode.rs:59)
-      t->name = simple;
-      t->ns = ns;
-      return t;
+      auto d = defs.find(full);
+      if (d == defs.end())
+        throw SchemaError("recursive named type " + full + ": a type that contains itself has no Arrow schema");
+      return clone_type(*d->second);   // apache-avro: Schema::Ref, resolved (beyond the reference, schema_translate.rs:51)
     }
     throw SchemaError("Unknown type: " + s);
   }
@@ -172,6 +195,7 @@ struct Parser {
         af.type = parse(*ft, r->ns);
         r->fields.push_back(std::move(af));
       }
+      defs[r->fullname()] = clone_type(*r);
       return r;
     }
     if (t == "enum") {
@@ -185,6 +209,7 @@ struct Parser {
         if (!seen.insert(s.str).second) throw SchemaError("Duplicate enum symbol " + s.str);
         e->symbols.push_back(s.str);
       }
+      defs[e->fullname()] = clone_type(*e);
       return e;
     }
     if (t == "array") {
@@ -208,6 +233,7 @@ struct Parser {
       if (!sz || !sz->is_number() || sz->num < 0 || sz->num != (double)(int64_t)sz->num)
         throw SchemaError("No `size` in fixed");
       f->size = (int64_t)sz->num;
+      defs[f->fullname()] = clone_type(*f);
       return f;
     }
     return parse_name(t, enclosing);
