@@ -291,7 +291,7 @@ def run(args, make_step=None, backend="nccl"):
     return rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc)
 
 
-PIPELINE_DEPTH = 3      # asynchronous calls in flight before the oldest is settled and freed
+PIPELINE_DEPTH = int(os.environ.get("BENCH_PIPELINE_DEPTH", "3"))      # asynchronous calls in flight before the oldest is settled and freed
 STREAMS = 1             # --streams: HIP streams the steps of the MAIN timed region are dealt to round-robin (default: one)
 OVERLAP_STREAMS = 3     # --overlap-streams: streams of the second, `overlapped` timed region (0 / 1 = skip it)
 SYNC_CALLS = False      # --sync-calls: every step waits for its own call (the pre-RH_ASYNC behaviour)
