@@ -339,15 +339,33 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   bool sat = false;
   constexpr int NDW = (S::K + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};
+  // No per-counter clamp (a counter beyond 16 bits flags the tile and k_emit sizes it again: the packed
+  // values of a flagged tile are never read), and when every counter of the wave is below 1024 the wave totals are
+  // reduced two counters per dword (64 x 1023 < 2^16: no carry between the halves) -- half the DPP reductions (k_size -2.6 %, profiles/r03ad_variants_ab.txt)
+  uint32_t allor = 0;
   static_for<0, S::K>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
     const uint32_t cv = c.cnt[k];
-    sat |= cv > 0xFFFFu;
-    const uint32_t c16 = cv > 0xFFFFu ? 0xFFFFu : cv;
-    packed[k / 2] |= (k & 1) ? c16 << 16 : c16;
-    const uint32_t v = wave_sum(cv);
-    if (lane == 0) s.wtot[k * NW + wave] = v;
+    allor |= cv;
+    packed[k / 2] = (k & 1) ? (packed[k / 2] | (cv << 16)) : cv;
   });
+  sat = allor > 0xFFFFu;
+  if (!__any(allor > 1023u)) {
+    static_for<0, NDW>([&](auto id) {
+      constexpr int d = decltype(id)::value;
+      const uint32_t v = wave_sum(packed[d]);
+      if (lane == 0) {
+        s.wtot[(2 * d) * NW + wave] = v & 0xFFFFu;
+        if constexpr (2 * d + 1 < S::K) s.wtot[(2 * d + 1) * NW + wave] = v >> 16;
+      }
+    });
+  } else {
+    static_for<0, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      const uint32_t v = wave_sum(c.cnt[k]);
+      if (lane == 0) s.wtot[k * NW + wave] = v;
+    });
+  }
   if constexpr (S::K > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const bool anysat = __any(sat);
   if (lane == 0 && (anysat || careful)) atomicOr(&s.misc[2], (anysat ? 1u : 0u) | (careful ? 2u : 0u));
