@@ -39,6 +39,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
   cpu_baseline  the oracle's C restatement of the reference walker ("port"), reference threading shape
                 (serial pack + one thread per chunk), timed on this box's host cores on the SAME records, best of 5:
                 with the workload's 8 chunks = 8 threads, and (`wide`) with min(64, cores) chunks.  Reported, not targeted.
+  other_configs (N=1 only) compact lines of BASELINE configs 2 and 3, the full schema at 1M records and the Arrow -> Avro
+                direction (2M rows, device-resident), so that the driver's run of this default command carries them.
   end_to_end    (N=1 only) the same workload through the HOST entry points of the C ABI -- host records in, host
                 Arrow batches out, PCIe both ways included -- so the CPU baseline has a like-for-like neighbour:
                 rh_decode_packed (one packed payload), rh_decode (one slice per record, what the CPython boundary
@@ -82,6 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--overlap-streams", type=int, default=OVERLAP_STREAMS,
                     help="streams of the second timed region reported as `overlapped` (0 = skip)")
     ap.add_argument("--sync-calls", action="store_true", help="every step waits for its own call (no RH_ASYNC pipelining)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of BASELINE configs 2-3, full1m and encode")
     ap.add_argument("--no-projection", action="store_true", help="skip config5_projection (profiler passes: only full-size launches)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="records of the CPU baseline (0 = the whole workload)")
@@ -187,6 +190,17 @@ def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sampl
         del res
     out["python_list_bytes"] = {"value": m / best, "wall_ms": best * 1e3, "records": m,
                                 "what": f"pyruhvro_amd.deserialize_array_threaded(list[bytes], schema, {num_chunks}) on a {m}-record sample"}
+    # BASELINE config 1: the reference's own CPU-runnable case, 10,000 records through the Python surface
+    small = recs[:10_000]
+    for _ in range(20):
+        P.deserialize_array_threaded(small, schema_json, num_chunks)
+    t = time.perf_counter()
+    for _ in range(200):
+        res = P.deserialize_array_threaded(small, schema_json, num_chunks)
+    per = (time.perf_counter() - t) / 200
+    del res
+    out["config1_python_10k"] = {"value": len(small) / per, "wall_ms": per * 1e3, "records": len(small),
+                                 "what": "BASELINE config 1: deserialize_array_threaded(10,000 records, schema, 8), host in -> host out, mean of 200 calls"}
     return out
 
 
@@ -439,6 +453,10 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
 
 
 def encode_main(args):
+    print(json.dumps(encode_line(args)))
+
+
+def encode_line(args):
     """Secondary line: Arrow -> Avro on the GPU, DEVICE-RESIDENT (rh_encode_device): the Arrow buffers of a batch that
     rh_decode_device left in HBM are read in place and the BinaryArrays of Avro datums are produced in HBM -- `value`
     is rows/s of that, like the decode line.  The host entry point (rh_encode: host batch in, host arrays out, PCIe
@@ -510,7 +528,7 @@ def encode_main(args):
         del out
         if best is None or w < best:
             best, hst = w, st
-    print(json.dumps({
+    return ({
         "metric": "Arrow rows/sec -> Avro (rh_encode_device: Arrow buffers and Avro datums resident in HBM)",
         "value": n * args.steps / wall, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
@@ -528,7 +546,59 @@ def encode_main(args):
                      "path_frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kern_ms else 0.0},
         "end_to_end": {"value": n / best, "unit": "rows/s", "wall_ms": best * 1e3,
                        "what": "rh_encode: host RecordBatch in -> host BinaryArrays out (PCIe both ways), best of 3",
-                       "stage_ms": {key: round(float(hst[key]), 3) for key in ("h2d_ms", "size_kernel_ms", "scan_kernel_ms", "emit_kernel_ms", "d2h_ms", "total_ms")}}}))
+                       "stage_ms": {key: round(float(hst[key]), 3) for key in ("h2d_ms", "size_kernel_ms", "scan_kernel_ms", "emit_kernel_ms", "d2h_ms", "total_ms")}}})
+
+
+def other_configs(local_rank: int = 0, steps: int = 60):
+    """BASELINE configs 2 and 3 (and the full schema at 1M records) and the Arrow -> Avro direction, in the DEFAULT line
+    so that the driver's run carries them: for each, the pipelined step, the synchronous call, the kernels' own times
+    (every 4th step carries timestamps) and the same steps dealt to OVERLAP_STREAMS streams.  At 1M records the input
+    (16-120 MB) lives in the 256 MB Infinity Cache and a call is 3-4 generations of resident waves: these are
+    launch / latency statements, not HBM-bandwidth ones."""
+    import argparse
+    import torch
+    from pyruhvro_amd import dist as rdist
+    out = {}
+    dev = torch.device("cuda", local_rank)
+    for name in ("flat4_1m", "cfg3_1m", "full1m"):
+        gen_cfg, n, k, desc = WORKLOADS[name]
+        shard = rdist.strong_shard(n, k, 1, 0)
+        step, info = gpu_step_factory(gen_cfg, shard, dev, local_rank)
+
+        def timed(f, nsteps, stats_every=0):
+            acc, cnt = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0}, 0
+            for _ in range(6):
+                f(False)
+            f.drain()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            sts = []
+            for i in range(nsteps):
+                sts += f(bool(stats_every) and i % stats_every == stats_every - 1) or []
+            sts += f.drain()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t) * 1e3 / nsteps
+            for st in sts:
+                cnt += 1
+                for key in acc:
+                    acc[key] += st.get(key, 0.0)
+            return wall, {key: v / max(cnt, 1) for key, v in acc.items()}
+        ms, kern = timed(step, steps, 4)
+        ov = step.overlapped(max(OVERLAP_STREAMS, 2))
+        ov_step = lambda w, _f=ov: _f()          # noqa: E731
+        ov_step.drain = ov.drain
+        oms, _ = timed(ov_step, steps)
+        alg = info["input_bytes"] + 8 * n + info["output_bytes"]
+        out[name] = {"workload": desc, "records": n, "ms_per_step": ms, "records_per_s": n / (ms * 1e-3),
+                     "sync_call_ms": step.sync_call_ms(), "overlapped_ms_per_step": oms,
+                     "kernel_ms": {"k_size": kern["size_kernel_ms"], "k_scan": kern["scan_kernel_ms"], "k_emit": kern["emit_kernel_ms"]},
+                     "emit_frac": alg / (kern["emit_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if kern["emit_kernel_ms"] > 0 else 0.0}
+        del step, ov, ov_step
+    enc = encode_line(argparse.Namespace(rows=2_000_000, steps=5, warmup=2, kernel="auto", stats_every=STATS_EVERY))
+    out["encode_2m_rows"] = {"workload": enc["config"]["workload"], "ms_per_step": enc["ms_per_step"], "rows_per_s": enc["value"],
+                             "kernel_ms": enc["config"]["kernel_ms"], "emit_frac": enc["roofline"]["frac"],
+                             "traffic": enc["roofline"]["traffic"], "end_to_end_rows_per_s": enc["end_to_end"]["value"]}
+    return out
 
 
 def config5_projection(step, ms_per_step_1gpu: float, num_chunks: int, reps: int = 40, overlapped_1gpu=None):
@@ -694,6 +764,9 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n) if args.cpu_sample else n, num_chunks)
     if not args.no_end_to_end and world == 1:
         out["end_to_end"] = end_to_end(gen_cfg, SCHEMAS[gen_cfg], n, num_chunks)
+    if not args.no_other_configs and not args.no_end_to_end and world == 1 and shard_whole:     # (profiler passes give --no-end-to-end)
+        run.step = None            # (the 10M-record buffers of the main workload are not needed any more)
+        out["other_configs"] = other_configs(0)
     print(json.dumps(out))
 
 
