@@ -850,7 +850,7 @@ struct rh_decode_call {
   const SpecKernel* sk = nullptr;
   uint64_t narrow_rows = 0, tile = 0, bpc64 = 0, payload = 0;
   uint32_t nblocks = 0;
-  uint64_t o_null = 32, o_tot = 0, ctrl_bytes = 0;
+  uint64_t o_null = 0, o_tot = 32, ctrl_bytes = 0;
   Lease ws, hctrl, dtab, prof_buf;
   std::unique_ptr<CtrlLease> ctrl;
   rh::KParams P;
@@ -932,7 +932,9 @@ struct rh_decode_call {
     HIPCHK(hipMemcpyAsync(dtab.ptr(), htab.ptr(), tab_bytes, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(ctrl->ptr() + 8, 0, 8, stream));    // clear the layout flag (and the ticket) of a refused optimistic attempt
     launch_tail(false);
+    // (not the totals: the host has them, and rh_k_publish may have zeroed the device copy of a refused attempt)
     HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), o_tot, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hctrl.ptr() + o_null, ctrl->ptr() + o_null, ctrl_bytes - o_null, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));      // also keeps htab alive until the table copy is done
     check_bad(hctrl.ptr());
   }
@@ -994,10 +996,11 @@ struct rh_decode_call {
     if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
     nblocks = (uint32_t)nblocks64;
 
-    // ---- workspace: [first_bad u64 | pad][nullcount u32 nnodes*k][totals u64 K*k] | errinfo | blocksum | blockbase
-    o_null = 32;     // control words first (program.h): first_bad, layout flag, arena bytes used
-    o_tot = align_up(o_null + 4ull * nnodes * k, 8);
-    ctrl_bytes = align_up(o_tot + 8ull * K * k, kAlign);
+    // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*kNullSlots]
+    //      workspace: errinfo | blocksum | blockbase | tileflag | lanecnt
+    o_tot = 32;      // control words first (program.h): first_bad, layout flag, arena bytes used
+    o_null = align_up(o_tot + 8ull * K * k, 8);
+    ctrl_bytes = align_up(o_null + 4ull * nnodes * k * rh::kNullSlots, kAlign);
     const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
     const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
@@ -1155,7 +1158,14 @@ struct rh_decode_call {
       s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
     }
     r.nullcount.assign((size_t)nnodes * k, 0);
-    std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
+    {
+      const uint32_t* slots = (const uint32_t*)(hctrl.ptr() + o_null);      // [nnodes][k][kNullSlots] (program.h)
+      for (size_t e = 0; e < (size_t)nnodes * k; e++) {
+        uint32_t sum = 0;
+        for (int sl = 0; sl < rh::kNullSlots; sl++) sum += slots[e * rh::kNullSlots + sl];
+        r.nullcount[e] = sum;
+      }
+    }
     hp.mark("host_layout");
 
     if (profile && sk) {

@@ -356,7 +356,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P,
 // (profiles/r03s_timeline_*.txt).
 // --------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t words) {
-  for (uint32_t i = threadIdx.x; i < words; i += kBlock) {
+  for (uint32_t i = blockIdx.x * (4 * kBlock) + threadIdx.x; i < words && i < (blockIdx.x + 1) * (4 * kBlock); i += kBlock) {
     host[i] = ctrl[i];
     ctrl[i] = 0;
   }
@@ -439,7 +439,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   report_errors(P, s.misc, L, g, tid, blockIdx.x);   // barrier inside: nullcnt + staging complete
   for (int i = tid; i < P.nnodes; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
-    if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
+    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * kNullSlots + (blockIdx.x & (kNullSlots - 1))], v);
   }
 }
 
@@ -471,7 +471,8 @@ extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, cons
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t words, void* stream) {
-  hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, words);
+  hipLaunchKernelGGL(rh::rh_k_publish, dim3((words + 4 * rh::kBlock - 1) / (4 * rh::kBlock)), dim3(rh::kBlock), 0, (hipStream_t)stream,
+                     (uint32_t*)ctrl, (uint32_t*)host, words);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {

@@ -472,7 +472,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(8);
   for (int i = tid; i < S::NNODES; i += T) {
     const uint32_t v = s.nullcnt[i];
-    if (v) atomicAdd(&P.nullcount[(size_t)i * P.k + g.chunk], v);
+    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * kNullSlots + (tile & (kNullSlots - 1))], v);
   }
   if constexpr (S::NB0 > 0) {   // the tile's domain-0 bitmap words (SCtx::put_word0): one lane per word
     for (uint32_t i = tid; i < (uint32_t)(S::NB0 * NW); i += T) {
