@@ -47,7 +47,7 @@ int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
 int rh_launch_layout(const rh::LParams* L, void* stream);
-int rh_launch_publish(void* ctrl, void* host, uint32_t words, void* stream);
+int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
@@ -864,8 +864,11 @@ struct rh_decode_call {
   bool child_bitmaps = false, fused = false, timed_size = false;
   double basis = 0;
   bool settled = false;         // finish() ran (or the call completed inside enqueue())
-  bool async = false;           // RH_ASYNC: mark the end of this call's work on the stream (DoneEvent)
+  bool async = false;           // RH_ASYNC: the call is settled later; without rh_k_publish its end is marked with a DoneEvent
   DoneEvent done;
+  bool published = false;       // rh_k_publish ran: hctrl holds the compact layout (summed null counts) behind a token
+  uint32_t token = 0;
+  uint64_t o_flag_h = 0;
 
   rh_decode_call(rh_schema* s_, const uint8_t* data, const uint64_t* offs, uint64_t dl, uint64_t n_, uint64_t nc, const rh_opts* o,
                bool stats, const ChunkGeo* g, rh_device_result& res)
@@ -919,6 +922,7 @@ struct rh_decode_call {
 
   void exact_tail() {      // totals are on the host: exactly sized arena, tables from the host
     ctrl->b.clean = false;
+    published = false;       // (the raw device layout is copied back below)
     layout_host();
     r.arena = Lease(dev_pool(), r.arena_bytes, device);
     Lease htab(pin_pool(), tab_bytes, device);
@@ -999,7 +1003,7 @@ struct rh_decode_call {
     // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*kNullSlots]
     //      workspace: errinfo | blocksum | blockbase | tileflag | lanecnt
     o_tot = 32;      // control words first (program.h): first_bad, layout flag, arena bytes used
-    o_null = align_up(o_tot + 8ull * K * k, 8);
+    o_null = align_up(o_tot + 8ull * K * k, 16);
     ctrl_bytes = align_up(o_null + 4ull * nnodes * k * rh::kNullSlots, kAlign);
     const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
     const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
@@ -1103,17 +1107,25 @@ struct rh_decode_call {
         throw HipError("k_scan / k_layout launch failed");
       launch_tail(true);                           // the layout kernel wrote offsets[0] = 0 itself
       hp.mark("layout+emit_launch");
-      // the control words go to the host from the call's last kernel, which also re-zeroes the block (rh_k_publish)
+      // the control words go to the host from the call's last kernel, which also re-zeroes the block (rh_k_publish) and
+      // writes a per-call token behind them: finish() spins on that word instead of waiting for a stream event
       void* hdev = nullptr;
       static const bool no_publish = env_long("RUHVRO_HIP_NO_PUBLISH", 0, 0, 1) != 0;
       if (!no_publish && hipHostGetDevicePointer(&hdev, hctrl.ptr(), 0) == hipSuccess && hdev) {
-        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(ctrl_bytes / 4), stream)) throw HipError("k_publish launch failed");
+        static std::atomic<uint32_t> next_token{1};
+        token = next_token.fetch_add(1);
+        if (token == 0) token = next_token.fetch_add(1);
+        o_flag_h = align_up(o_null + 4ull * nnodes * k, 8);                 // host layout: head | compact null counts | token
+        *(volatile uint32_t*)(hctrl.ptr() + o_flag_h) = 0;
+        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, stream))
+          throw HipError("k_publish launch failed");
         ctrl->b.clean = true;
+        published = true;
       } else {
         (void)hipGetLastError();
         HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+        if (async) done.record(device, stream);
       }
-      if (async) done.record(device, stream);
       hp.mark("d2h_enqueue");
     }
   }
@@ -1123,8 +1135,28 @@ struct rh_decode_call {
     settled = true;
     HIPCHK(hipSetDevice(device));
     if (fused) {
-      if (done.e) done.wait();                     // this call only: later calls stay queued behind it
-      else HIPCHK(hipStreamSynchronize(stream));
+      if (published) {
+        // spin on the token rh_k_publish stores last into this call's pinned block: this call only (later calls stay
+        // queued behind it), no event in the stream, and sooner than a stream wait returns
+        volatile uint32_t* flag = (volatile uint32_t*)(hctrl.ptr() + o_flag_h);
+        for (uint32_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != token;) {
+          if ((++spins & 0xFFFFu) == 0) {              // a failed launch or a fault must not hang the caller
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {                     // everything on the stream is done: the token must be there
+              if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != token) throw HipError("rh_k_publish finished without publishing its token");
+              break;
+            }
+            if (q != hipErrorNotReady) throw HipError(std::string("stream failed while waiting for a decode call: ") + hipGetErrorString(q));
+          }
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+      } else if (done.e) {
+        done.wait();                               // this call only: later calls stay queued behind it
+      } else {
+        HIPCHK(hipStreamSynchronize(stream));
+      }
       hp.mark("sync");
       check_bad(hctrl.ptr());
       if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
@@ -1158,7 +1190,9 @@ struct rh_decode_call {
       s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
     }
     r.nullcount.assign((size_t)nnodes * k, 0);
-    {
+    if (published) {           // rh_k_publish summed the slots: one word per (node, chunk)
+      std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
+    } else {
       const uint32_t* slots = (const uint32_t*)(hctrl.ptr() + o_null);      // [nnodes][k][kNullSlots] (program.h)
       for (size_t e = 0; e < (size_t)nnodes * k; e++) {
         uint32_t sum = 0;

@@ -355,11 +355,30 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P,
 // (4.5 us) plus the fill kernel (1.7 us) that re-zeroed the block, which were 4-15 % of a 1M-record call
 // (profiles/r03s_timeline_*.txt).
 // --------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t words) {
-  for (uint32_t i = blockIdx.x * (4 * kBlock) + threadIdx.x; i < words && i < (blockIdx.x + 1) * (4 * kBlock); i += kBlock) {
+// The null counts leave as ONE word per (node, chunk): the kNullSlots addresses the workgroups added into are summed here.
+// The LAST store is a token at host[flag_word] (system scope, behind a system-scope fence of every thread's stores and a
+// barrier): the host spins on that word in its pinned block instead of waiting for a stream event -- an event record
+// between two calls cost the GPU 5.7 us of idle time per call (profiles/r03aj_timeline.txt), and the spin sees the
+// token ~3 us sooner than hipStreamSynchronize returns (tools/synclat.hip).
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t head_words,
+                                                                 uint32_t null_entries, uint32_t flag_word, uint32_t token) {
+  for (uint32_t i = threadIdx.x; i < head_words; i += kBlock) {      // control words + chunk totals, as they are
     host[i] = ctrl[i];
     ctrl[i] = 0;
   }
+  uint32_t* slots = ctrl + head_words;                               // [null_entries][kNullSlots]
+  for (uint32_t e = threadIdx.x; e < null_entries; e += kBlock) {
+    const v4w* p = reinterpret_cast<const v4w*>(slots + (size_t)e * kNullSlots);
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < kNullSlots / 4; q++) { const v4w x = p[q]; sum += x.x + x.y + x.z + x.w; }
+    host[head_words + e] = sum;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < null_entries * (uint32_t)kNullSlots; i += kBlock) slots[i] = 0;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host + flag_word, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // true when the call must not emit: a malformed record was found by the size pass, or the layout kernel said no
@@ -470,9 +489,10 @@ extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, cons
                      nbuf, k, ctrl);
   return (int)hipGetLastError();
 }
-extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t words, void* stream) {
-  hipLaunchKernelGGL(rh::rh_k_publish, dim3((words + 4 * rh::kBlock - 1) / (4 * rh::kBlock)), dim3(rh::kBlock), 0, (hipStream_t)stream,
-                     (uint32_t*)ctrl, (uint32_t*)host, words);
+extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token,
+                                 void* stream) {
+  hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, head_words,
+                     null_entries, flag_word, token);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
