@@ -80,6 +80,16 @@ typedef struct {
    * reference's split of these n records (n / num_chunks). */
   uint64_t chunk_rows;
   rh_stats* device_stats; /* optional, room for n_devices entries: per-shard stage timings of a multi-GPU call */
+  /* Streaming hand-over of the record slices (rh_decode only, ABI version 4): a producer thread of the caller fills
+   * ptrs[] / lens[] front to back WHILE the call runs and publishes its progress in *ready -- the number of leading
+   * entries that are valid (monotonic, stored with release order; UINT64_MAX = the producer gave up, the call fails
+   * with RH_ERR_ARGUMENT).  The engine gathers a chunk group into pinned memory as soon as its entries are there, so
+   * the H2D copy, the kernels and the D2H copy of the first groups overlap the producer's work on the later ones.
+   * *gathered (optional) is the engine's answer: the number of leading records whose BYTES it has copied and will
+   * not read again -- the caller may let go of them (the CPython boundary drops its references while the tail of the
+   * call is still on the PCIe link).  NULL / NULL = every entry is valid at entry, the classic call. */
+  const uint64_t* ready;
+  uint64_t* gathered;
 } rh_opts;
 
 /* Kernel selection (rh_opts.flags).  Both forms are HIP kernels running the same field handlers and

@@ -31,10 +31,11 @@ class RhStats(C.Structure):
 
 
 class RhOpts(C.Structure):
-    """rh_opts (ABI version 3).  Build with make_opts()."""
+    """rh_opts (ABI version 4).  Build with make_opts()."""
     _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
                 ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("reserved0", C.c_uint32),
-                ("chunk_rows", C.c_uint64), ("device_stats", C.POINTER(RhStats))]
+                ("chunk_rows", C.c_uint64), ("device_stats", C.POINTER(RhStats)),
+                ("ready", C.POINTER(C.c_uint64)), ("gathered", C.POINTER(C.c_uint64))]   # streaming hand-over (rh_decode): NULL = off
 
 
 def make_opts(device: int = -1, kernel: int = 0, stream=None, devices=None, chunk_rows: int = 0):

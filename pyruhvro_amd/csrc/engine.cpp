@@ -876,7 +876,7 @@ struct rh_decode_call {
         want_stats(stats), r(res) {
     std::memset(&st, 0, sizeof st);
     if (g) { geo_v = *g; geo = &geo_v; }
-    opts.devices = nullptr; opts.n_devices = 0; opts.device_stats = nullptr;   // (not used below; never dangling)
+    opts.devices = nullptr; opts.n_devices = 0; opts.device_stats = nullptr; opts.ready = nullptr; opts.gathered = nullptr;   // (not used below; never dangling)
   }
 
   void check_bad(const uint8_t* h) {
@@ -1718,8 +1718,24 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
   }
   hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
   if (multi && user_stream) throw std::invalid_argument("a multi-device call runs on the engine's own streams (stream must be NULL)");
+  // streaming hand-over (rh_opts.ready): the producer is still filling ptrs[] / lens[]; entries [0, *ready) are valid
+  const uint64_t* const ready_ctr = (opts && src.slices()) ? opts->ready : nullptr;
+  uint64_t* const gathered_ctr = (opts && src.slices()) ? opts->gathered : nullptr;
+  auto wait_ready = [&](uint64_t upto) {
+    if (!ready_ctr) return;
+    for (uint32_t spins = 0;; spins++) {
+      const uint64_t v = __atomic_load_n(ready_ctr, __ATOMIC_ACQUIRE);
+      if (v == ~0ull) throw std::invalid_argument("the producer of the record slices gave up");
+      if (v >= upto) return;
+      if (spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  };
+  const bool streaming = ready_ctr != nullptr && n >= 4096 && k >= 2 && !(opts && opts->stream);
+  if (ready_ctr && !streaming) wait_ready(n);        // too small to pipeline: the classic call once everything is there
   uint64_t bytes = 0;
-  if (src.slices()) {          // payload size decides whether the call is pipelined: a parallel sum of the lengths
+  if (streaming) {
+    bytes = ~0ull >> 1;        // unknown yet: pipelined by construction (groups of chunks start as their entries arrive)
+  } else if (src.slices()) {          // payload size decides whether the call is pipelined: a parallel sum of the lengths
     const unsigned nt = n >= (1u << 16) ? std::min(hw, 16u) : 1u;
     std::vector<uint64_t> part(nt, 0);
     run_threads(nt, [&](unsigned t) {
@@ -1815,8 +1831,10 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
           if (sh.c1 > sh.c0) {
             HIPCHK(hipSetDevice(sh.device));
             const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
+            if (streaming) wait_ready(r1);
             ready.block[g] = src.slices() ? gather_slices(src, r0, r1 - r0, sh.device, pack_threads, par)
                                           : stage_packed_range(src, r0, r1 - r0, sh.device, pack_threads, par);
+            if (gathered_ctr) __atomic_store_n(gathered_ctr, r1, __ATOMIC_RELEASE);   // (shards are gathered in row order)
             Timeline::mark((uint32_t)g, "gathered");
           }
         } catch (...) {

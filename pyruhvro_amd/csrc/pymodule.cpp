@@ -11,6 +11,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <chrono>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <cstddef>
 #include <memory>
@@ -128,14 +132,49 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   std::unique_ptr<const uint8_t*[]> ptrs(new const uint8_t*[(size_t)n + 1]);
   std::unique_ptr<uint64_t[]> lens(new uint64_t[(size_t)n + 1]);
   constexpr size_t kPayload = offsetof(PyBytesObject, ob_sval);
-  auto drop_refs = [&](Py_ssize_t upto) {
+  auto drop_range = [&](Py_ssize_t from, Py_ssize_t upto) {
     constexpr Py_ssize_t kAheadD = 24;
-    for (Py_ssize_t i = 0; i < upto; i++) {
+    for (Py_ssize_t i = from; i < upto; i++) {
       if (i + kAheadD < upto) __builtin_prefetch(ptrs[(size_t)(i + kAheadD)] - kPayload, 1, 1);
       PyObject* o = (PyObject*)(ptrs[(size_t)i] - kPayload);
       Py_DECREF(o);
     }
   };
+  const uint32_t k = rh_clamp_chunks((uint64_t)n, num_chunks);
+  ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
+  rh_opts opts;
+  std::memset(&opts, 0, sizeof opts);
+  opts.device = device;
+  opts.flags = kernel;
+  opts.stream = (void*)(uintptr_t)stream;
+  if (!devices.empty()) { opts.devices = devices.data(); opts.n_devices = (uint32_t)devices.size(); }
+  rh_stats st;
+  std::memset(&st, 0, sizeof st);
+  char* err = nullptr;
+  uint32_t out_k = 0;
+  int rc = RH_OK;
+  // Large lists are handed over while they are still being extracted (rh_opts.ready / gathered): the engine runs on its
+  // own thread from the start, gathers a chunk group as soon as its (pointer, length) entries exist -- so the copies and
+  // the kernels of the first groups overlap the extraction of the later ones -- and says which records it has copied;
+  // their references are dropped while the tail of the call is still on the PCIe link.  (A 2M-record list: the
+  // extraction and release loops are 2/3 of the wall time of the serial form, scripts/pyprof_list_bytes.py.)
+  static const long stream_min = [] {
+    const char* e = std::getenv("PYRUHVRO_STREAM_MIN");
+    return e && *e ? std::atol(e) : 65536l;
+  }();
+  const bool streaming = stream_min >= 0 && (long)n >= stream_min && n >= 2 && stream == 0;
+  std::atomic<uint64_t> ready{0}, gathered{0};
+  std::atomic<bool> finished{false};
+  std::thread worker;
+  if (streaming) {
+    static_assert(sizeof(std::atomic<uint64_t>) == sizeof(uint64_t), "plain 64-bit atomics");
+    opts.ready = reinterpret_cast<const uint64_t*>(&ready);
+    opts.gathered = reinterpret_cast<uint64_t*>(&gathered);
+    worker = std::thread([&] {                     // (never touches Python)
+      rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+      finished.store(true, std::memory_order_release);
+    });
+  }
   // The list's objects are scattered over the heap: one cache miss per header.  The pointer array is contiguous, so
   // the headers 24 items ahead are prefetched while this one is read (a shuffled 2M-record list: 134 -> 103 ms).
   constexpr Py_ssize_t kAhead = 24;
@@ -157,28 +196,51 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
     lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
     done = i + 1;
+    if (streaming && (done & 8191) == 0) ready.store((uint64_t)done, std::memory_order_release);
   }
   if (!ok) {
-    drop_refs(done);
+    if (streaming) {
+      ready.store(~0ull, std::memory_order_release);          // the engine call fails; nothing of it is used
+      PyObject *et, *ev, *tb;
+      PyErr_Fetch(&et, &ev, &tb);
+      Py_BEGIN_ALLOW_THREADS
+      worker.join();
+      Py_END_ALLOW_THREADS
+      PyErr_Restore(et, ev, tb);
+      for (uint32_t c = 0; c < k; c++)
+        if (chunks[c].release) chunks[c].release(&chunks[c]);
+      if (err) rh_free_string(err);
+    }
+    drop_range(0, done);
+    std::free(chunks);
     return nullptr;
   }
-  const uint32_t k = rh_clamp_chunks((uint64_t)n, num_chunks);
-  ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
-  rh_opts opts;
-  std::memset(&opts, 0, sizeof opts);
-  opts.device = device;
-  opts.flags = kernel;
-  opts.stream = (void*)(uintptr_t)stream;
-  if (!devices.empty()) { opts.devices = devices.data(); opts.n_devices = (uint32_t)devices.size(); }
-  rh_stats st;
-  std::memset(&st, 0, sizeof st);
-  char* err = nullptr;
-  uint32_t out_k = 0;
-  int rc;
-  Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
-  rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
-  Py_END_ALLOW_THREADS
-  drop_refs(n);
+  if (streaming) {
+    ready.store((uint64_t)n, std::memory_order_release);
+    // drop the references of the records the engine has copied, while it works on the rest; the GIL is released in
+    // between (py.detach(...), src/lib.rs:82-86)
+    Py_ssize_t released = 0;
+    while (!finished.load(std::memory_order_acquire)) {
+      const Py_ssize_t upto = (Py_ssize_t)std::min<uint64_t>(gathered.load(std::memory_order_acquire), (uint64_t)n);
+      if (upto > released) {
+        drop_range(released, upto);
+        released = upto;
+      } else {
+        Py_BEGIN_ALLOW_THREADS
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        Py_END_ALLOW_THREADS
+      }
+    }
+    Py_BEGIN_ALLOW_THREADS
+    worker.join();
+    Py_END_ALLOW_THREADS
+    drop_range(released, n);
+  } else {
+    Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
+    rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+    Py_END_ALLOW_THREADS
+    drop_range(0, n);
+  }
   if (rc != RH_OK) {
     std::free(chunks);
     return raise_from(rc, err);

@@ -384,3 +384,48 @@ def test_stats_json_line(tmp_path):
     assert a["stats"]["emit_kernel_ms"] > 0 and a["stats"]["total_ms"] >= a["stats"]["emit_kernel_ms"] and a["stats"]["output_bytes"] > 0
     assert [d["device"] for d in b["devices"]] == [0, 0] and sum(d["stats"]["records"] for d in b["devices"]) == 3000
     assert c["rc"] == 2                                       # RH_ERR_DECODE: the line is printed for failed calls too
+
+
+def test_streaming_hand_over_of_the_list(tmp_path):
+    """Large lists are handed to the engine WHILE they are extracted (rh_opts.ready / gathered, pymodule.cpp): the same
+    batches, the same TypeError for a non-bytes element wherever it sits, bytearray elements copied, the reference's
+    message for a malformed record.  PYRUHVRO_STREAM_MIN is read once per process, so the streamed calls run in a child
+    (the whole GPU suite also passes with PYRUHVRO_STREAM_MIN=1, scripts/gpu_r03ak.sh)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, pyruhvro_amd as P
+from arrow_compare import assert_batches_identical
+from avrogen import synth
+from avrogen.schemas import SCHEMAS
+from oracle import c_walker
+S = SCHEMAS["full"]
+recs = synth.records("full", 20011)
+for k in (2, 8, 100):
+    got = P.deserialize_array_threaded(recs, S, k)
+    for g, e in zip(got, c_walker.decode_threaded(recs, S, k)):
+        assert_batches_identical(g, e)
+mixed = [bytearray(r) if i %% 7 == 0 else r for i, r in enumerate(recs[:3000])]
+for g, e in zip(P.deserialize_array_threaded(mixed, S, 3), c_walker.decode_threaded(recs[:3000], S, 3)):
+    assert_batches_identical(g, e)
+for pos in (0, 1, 8191, 8192, 15000, 20010):
+    bad = list(recs); bad[pos] = "not bytes"
+    try:
+        P.deserialize_array_threaded(bad, S, 8); raise SystemExit("no TypeError")
+    except TypeError as e:
+        assert "list element %%d" %% pos in str(e), str(e)
+for pos in (0, 9000, 20010):
+    bad = list(recs); bad[pos] = recs[pos][:5]
+    try:
+        P.deserialize_array_threaded(bad, S, 8); raise SystemExit("no ValueError")
+    except ValueError as e:
+        try:
+            c_walker.decode_threaded(bad, S, 8); raise SystemExit("oracle accepted it")
+        except ValueError as eo:
+            assert str(e) == str(eo), (str(e), str(eo))
+print("streamed ok")
+''' % (root, os.path.join(root, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYRUHVRO_STREAM_MIN="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "streamed ok" in p.stdout, p.stdout + p.stderr
