@@ -1599,6 +1599,7 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
       own = gather_slices(src, r0, n, device, pack_threads,
                           [](unsigned nt, const std::function<void(unsigned)>& f) { run_threads(nt, f); });
       pre = &own;
+      if (opts && opts->gathered && !geo_in) __atomic_store_n(opts->gathered, r1, __ATOMIC_RELEASE);   // (the unpipelined call)
     }
     pin = std::move(pre->pin);
     pack_ms = pre->pack_ms;

@@ -9,6 +9,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -126,6 +127,12 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     return nullptr;
   }
   const Py_ssize_t n = PyList_GET_SIZE(list);
+  // PYRUHVRO_PYPROF=1: one stderr line per call with the milliseconds of the boundary's own phases
+  static const bool pyprof = [] { const char* e = std::getenv("PYRUHVRO_PYPROF"); return e && *e && *e != '0'; }();
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  double ms_alloc = 0, ms_extract = 0, ms_tail = 0;
+  (void)ms_alloc;
   // one (pointer, length) per record, uninitialised (2 x 8 bytes x n): every slot is written below.  A reference is
   // held on every bytes object while the GIL is released; the object is recovered from its payload pointer afterwards
   // (payload = object + offsetof(PyBytesObject, ob_sval)), so no third array is kept.
@@ -153,11 +160,17 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   char* err = nullptr;
   uint32_t out_k = 0;
   int rc = RH_OK;
-  // Large lists are handed over while they are still being extracted (rh_opts.ready / gathered): the engine runs on its
-  // own thread from the start, gathers a chunk group as soon as its (pointer, length) entries exist -- so the copies and
-  // the kernels of the first groups overlap the extraction of the later ones -- and says which records it has copied;
-  // their references are dropped while the tail of the call is still on the PCIe link.  (A 2M-record list: the
-  // extraction and release loops are 2/3 of the wall time of the serial form, scripts/pyprof_list_bytes.py.)
+  // Large lists are BORROWED and handed over while they are still being extracted (rh_opts.ready / gathered):
+  //  * the engine runs on its own thread from the start and gathers a chunk group into pinned memory as soon as its
+  //    (pointer, length) entries exist, so the copies and the kernels of the first groups overlap the extraction;
+  //  * the entries are read by a few helper threads, READ-ONLY: this thread holds the GIL until the engine reports that
+  //    it has copied every record's bytes (`gathered == n`), so no object of the list can change or die meanwhile and no
+  //    reference is taken -- the two passes over 2M object headers that taking and dropping references cost were 2/3 of
+  //    the serial call (scripts/pyprof_list_bytes.py); bytearray elements are borrowed the same way;
+  //  * from then on nothing points into the Python heap any more and the GIL is released for the rest of the call
+  //    (py.detach(...), src/lib.rs:82-86).  The GIL is held for a few milliseconds per million records -- less than the
+  //    reference holds it for its own extraction (extract_bytes_list, src/lib.rs).
+  // Small lists take the classic form: one reference per object, GIL released around the whole engine call.
   static const long stream_min = [] {
     const char* e = std::getenv("PYRUHVRO_STREAM_MIN");
     return e && *e ? std::atol(e) : 65536l;
@@ -166,6 +179,11 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   std::atomic<uint64_t> ready{0}, gathered{0};
   std::atomic<bool> finished{false};
   std::thread worker;
+  Py_ssize_t done = 0;
+  bool ok = true;
+  ms_alloc = ms_since(t_start);
+  const auto t_extract = std::chrono::steady_clock::now();
+  std::chrono::steady_clock::time_point t_tail;
   if (streaming) {
     static_assert(sizeof(std::atomic<uint64_t>) == sizeof(uint64_t), "plain 64-bit atomics");
     opts.ready = reinterpret_cast<const uint64_t*>(&ready);
@@ -174,73 +192,110 @@ PyObject* py_decode(PyObject*, PyObject* args) {
       rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
       finished.store(true, std::memory_order_release);
     });
-  }
-  // The list's objects are scattered over the heap: one cache miss per header.  The pointer array is contiguous, so
-  // the headers 24 items ahead are prefetched while this one is read (a shuffled 2M-record list: 134 -> 103 ms).
-  constexpr Py_ssize_t kAhead = 24;
-  Py_ssize_t done = 0;
-  bool ok = true;
-  for (Py_ssize_t i = 0; i < n; i++) {
-    if (i + kAhead < n) __builtin_prefetch(PyList_GET_ITEM(list, i + kAhead), 1, 1);
-    PyObject* it = PyList_GET_ITEM(list, i);
-    if (PyBytes_Check(it)) {
-      Py_INCREF(it);
-    } else if (PyByteArray_Check(it)) {
-      it = PyBytes_FromStringAndSize(PyByteArray_AS_STRING(it), PyByteArray_GET_SIZE(it));   // copied, like PyBackedBytes
-      if (!it) { ok = false; break; }
-    } else {
-      PyErr_Format(PyExc_TypeError, "list element %zd: expected bytes, got %s", i, Py_TYPE(it)->tp_name);
-      ok = false;
-      break;
+    // read-only extraction, blocks of kBlk entries dealt round-robin to the helpers; `ready` follows the done prefix
+    constexpr Py_ssize_t kBlk = 16384;
+    const Py_ssize_t nblk = (n + kBlk - 1) / kBlk;
+    const unsigned nth = (unsigned)std::max<long>(1, std::min<long>({8l, (long)std::thread::hardware_concurrency() / 4, (long)nblk}));
+    std::unique_ptr<std::atomic<unsigned char>[]> blk_done(new std::atomic<unsigned char>[(size_t)nblk]);
+    for (Py_ssize_t b = 0; b < nblk; b++) blk_done[(size_t)b].store(0, std::memory_order_relaxed);
+    std::atomic<Py_ssize_t> first_bad{n};
+    PyObject** items = PySequence_Fast_ITEMS(list);          // (a list: its item array, stable while the GIL is held)
+    auto extract = [&](unsigned t) {
+      for (Py_ssize_t b = t; b < nblk; b += nth) {
+        const Py_ssize_t lo = b * kBlk, hi = std::min<Py_ssize_t>(lo + kBlk, n);
+        if (first_bad.load(std::memory_order_relaxed) < lo) break;           // a lower element is already known bad
+        for (Py_ssize_t i = lo; i < hi; i++) {
+          if (i + 24 < hi) __builtin_prefetch(items[i + 24], 0, 1);
+          PyObject* it = items[i];
+          if (PyBytes_Check(it)) {
+            ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
+            lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
+          } else if (PyByteArray_Check(it)) {
+            ptrs[(size_t)i] = (const uint8_t*)PyByteArray_AS_STRING(it);
+            lens[(size_t)i] = (uint64_t)PyByteArray_GET_SIZE(it);
+          } else {
+            Py_ssize_t cur = first_bad.load(std::memory_order_relaxed);
+            while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+            break;
+          }
+        }
+        blk_done[(size_t)b].store(1, std::memory_order_release);
+      }
+    };
+    std::vector<std::thread> helpers;
+    for (unsigned t = 1; t < nth; t++) helpers.emplace_back(extract, t);
+    // this thread takes its share too, then follows the prefix of finished blocks
+    extract(0);
+    Py_ssize_t prefix = 0;
+    for (;;) {
+      while (prefix < nblk && blk_done[(size_t)prefix].load(std::memory_order_acquire)) prefix++;
+      const Py_ssize_t bad = first_bad.load(std::memory_order_relaxed);
+      const Py_ssize_t upto = std::min<Py_ssize_t>(std::min<Py_ssize_t>(prefix * kBlk, n), bad);
+      ready.store((uint64_t)upto, std::memory_order_release);
+      if (prefix == nblk || bad < n) break;
+      std::this_thread::yield();
     }
-    ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
-    lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
-    done = i + 1;
-    if (streaming && (done & 8191) == 0) ready.store((uint64_t)done, std::memory_order_release);
-  }
-  if (!ok) {
-    if (streaming) {
+    for (auto& h : helpers) h.join();
+    const Py_ssize_t bad = first_bad.load();
+    ms_extract = ms_since(t_extract);
+    t_tail = std::chrono::steady_clock::now();
+    if (bad < n) {
       ready.store(~0ull, std::memory_order_release);          // the engine call fails; nothing of it is used
-      PyObject *et, *ev, *tb;
-      PyErr_Fetch(&et, &ev, &tb);
       Py_BEGIN_ALLOW_THREADS
       worker.join();
       Py_END_ALLOW_THREADS
-      PyErr_Restore(et, ev, tb);
       for (uint32_t c = 0; c < k; c++)
         if (chunks[c].release) chunks[c].release(&chunks[c]);
       if (err) rh_free_string(err);
+      std::free(chunks);
+      PyErr_Format(PyExc_TypeError, "list element %zd: expected bytes, got %s", bad, Py_TYPE(items[bad])->tp_name);
+      return nullptr;
     }
-    drop_range(0, done);
-    std::free(chunks);
-    return nullptr;
-  }
-  if (streaming) {
     ready.store((uint64_t)n, std::memory_order_release);
-    // drop the references of the records the engine has copied, while it works on the rest; the GIL is released in
-    // between (py.detach(...), src/lib.rs:82-86)
-    Py_ssize_t released = 0;
-    while (!finished.load(std::memory_order_acquire)) {
-      const Py_ssize_t upto = (Py_ssize_t)std::min<uint64_t>(gathered.load(std::memory_order_acquire), (uint64_t)n);
-      if (upto > released) {
-        drop_range(released, upto);
-        released = upto;
-      } else {
-        Py_BEGIN_ALLOW_THREADS
-        std::this_thread::sleep_for(std::chrono::microseconds(50));
-        Py_END_ALLOW_THREADS
-      }
-    }
+    // the GIL stays with this thread until the engine has copied every record (or gave up): then nothing borrowed is in use
+    while (!finished.load(std::memory_order_acquire) && gathered.load(std::memory_order_acquire) < (uint64_t)n)
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
     Py_BEGIN_ALLOW_THREADS
     worker.join();
     Py_END_ALLOW_THREADS
-    drop_range(released, n);
+    done = n;
   } else {
+    // The list's objects are scattered over the heap: one cache miss per header.  The pointer array is contiguous, so
+    // the headers 24 items ahead are prefetched while this one is read (a shuffled 2M-record list: 134 -> 103 ms).
+    constexpr Py_ssize_t kAhead = 24;
+    for (Py_ssize_t i = 0; i < n; i++) {
+      if (i + kAhead < n) __builtin_prefetch(PyList_GET_ITEM(list, i + kAhead), 1, 1);
+      PyObject* it = PyList_GET_ITEM(list, i);
+      if (PyBytes_Check(it)) {
+        Py_INCREF(it);
+      } else if (PyByteArray_Check(it)) {
+        it = PyBytes_FromStringAndSize(PyByteArray_AS_STRING(it), PyByteArray_GET_SIZE(it));   // copied, like PyBackedBytes
+        if (!it) { ok = false; break; }
+      } else {
+        PyErr_Format(PyExc_TypeError, "list element %zd: expected bytes, got %s", i, Py_TYPE(it)->tp_name);
+        ok = false;
+        break;
+      }
+      ptrs[(size_t)i] = (const uint8_t*)PyBytes_AS_STRING(it);
+      lens[(size_t)i] = (uint64_t)PyBytes_GET_SIZE(it);
+      done = i + 1;
+    }
+    if (!ok) {
+      drop_range(0, done);
+      std::free(chunks);
+      return nullptr;
+    }
+    ms_extract = ms_since(t_extract);
+    t_tail = std::chrono::steady_clock::now();
     Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
     rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
     Py_END_ALLOW_THREADS
     drop_range(0, n);
   }
+  ms_tail = ms_since(t_tail);
+  if (pyprof)
+    std::fprintf(stderr, "[pyruhvro pyprof] n=%zd streaming=%d alloc+setup=%.2f extract=%.2f engine_tail+release=%.2f total=%.2f ms\n", n,
+                 (int)streaming, ms_alloc, ms_extract, ms_tail, ms_since(t_start));
   if (rc != RH_OK) {
     std::free(chunks);
     return raise_from(rc, err);
