@@ -104,7 +104,7 @@ typedef struct {
  * The result's device buffers are valid in stream order on rh_opts.stream, like any asynchronous HIP work; what the
  * HOST learns from a call -- the first malformed record (the in-order join of deserialize.rs:115-119), row counts,
  * null counts, an arena that has to be re-laid-out -- is settled by rh_device_result_wait(), which every accessor of
- * an unsettled result also runs first.  The input buffers must stay alive until then.  A schema's first call on a
+ * an unsettled result also runs first.  The input buffers AND the compiled schema must stay alive until then.  A schema's first call on a
  * device (no size history to reserve the arena from) completes synchronously whatever the flag says.  This is how a
  * pipeline of small batches keeps the GPU busy: a 1M-record call is 0.15 ms of kernels, and a synchronous call adds
  * ~25 us of host turn-around during which the GPU idles. */

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <system_error>
 #include <atomic>
 #include <string>
 #include <cstddef>
@@ -175,7 +176,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     const char* e = std::getenv("PYRUHVRO_STREAM_MIN");
     return e && *e ? std::atol(e) : 65536l;
   }();
-  const bool streaming = stream_min >= 0 && (long)n >= stream_min && n >= 2 && stream == 0;
+  bool streaming = stream_min >= 0 && (long)n >= stream_min && n >= 2 && stream == 0;
   std::atomic<uint64_t> ready{0}, gathered{0};
   std::atomic<bool> finished{false};
   std::thread worker;
@@ -188,11 +189,19 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     static_assert(sizeof(std::atomic<uint64_t>) == sizeof(uint64_t), "plain 64-bit atomics");
     opts.ready = reinterpret_cast<const uint64_t*>(&ready);
     opts.gathered = reinterpret_cast<uint64_t*>(&gathered);
-    worker = std::thread([&] {                     // (never touches Python)
-      rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
-      finished.store(true, std::memory_order_release);
-    });
-    // read-only extraction, blocks of kBlk entries dealt round-robin to the helpers; `ready` follows the done prefix
+    try {
+      worker = std::thread([&] {                     // (never touches Python)
+        rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+        finished.store(true, std::memory_order_release);
+      });
+    } catch (const std::system_error&) {             // no thread to be had: the classic form below
+      streaming = false;
+      opts.ready = nullptr;
+      opts.gathered = nullptr;
+    }
+  }
+  if (streaming) {
+    // read-only extraction, blocks of kBlk entries claimed in order by the helpers; `ready` follows the done prefix
     constexpr Py_ssize_t kBlk = 16384;
     const Py_ssize_t nblk = (n + kBlk - 1) / kBlk;
     const unsigned nth = (unsigned)std::max<long>(1, std::min<long>({8l, (long)std::thread::hardware_concurrency() / 4, (long)nblk}));
@@ -200,8 +209,9 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     for (Py_ssize_t b = 0; b < nblk; b++) blk_done[(size_t)b].store(0, std::memory_order_relaxed);
     std::atomic<Py_ssize_t> first_bad{n};
     PyObject** items = PySequence_Fast_ITEMS(list);          // (a list: its item array, stable while the GIL is held)
-    auto extract = [&](unsigned t) {
-      for (Py_ssize_t b = t; b < nblk; b += nth) {
+    std::atomic<Py_ssize_t> next_blk{0};
+    auto extract = [&]() {
+      for (Py_ssize_t b; (b = next_blk.fetch_add(1, std::memory_order_relaxed)) < nblk;) {
         const Py_ssize_t lo = b * kBlk, hi = std::min<Py_ssize_t>(lo + kBlk, n);
         if (first_bad.load(std::memory_order_relaxed) < lo) break;           // a lower element is already known bad
         for (Py_ssize_t i = lo; i < hi; i++) {
@@ -223,9 +233,11 @@ PyObject* py_decode(PyObject*, PyObject* args) {
       }
     };
     std::vector<std::thread> helpers;
-    for (unsigned t = 1; t < nth; t++) helpers.emplace_back(extract, t);
+    try {
+      for (unsigned t = 1; t < nth; t++) helpers.emplace_back(extract);
+    } catch (const std::system_error&) {}            // fewer helpers: the blocks are claimed dynamically
     // this thread takes its share too, then follows the prefix of finished blocks
-    extract(0);
+    extract();
     Py_ssize_t prefix = 0;
     for (;;) {
       while (prefix < nblk && blk_done[(size_t)prefix].load(std::memory_order_acquire)) prefix++;
