@@ -121,3 +121,45 @@ def test_first_call_of_a_schema_completes_synchronously():
     for g, e in zip(r.to_host(), c_walker.decode_threaded(recs, schema, 2)):
         assert_batches_identical(g, e)
     r.free()
+
+
+def test_async_calls_from_several_threads_on_their_own_streams():
+    """Four host threads, each with its own HIP stream, keep three RH_ASYNC calls in flight and settle them in order --
+    the pools (control blocks, workspaces, arenas, pinned blocks), the token spin and the publish kernel under
+    concurrency; every result buffer-identical to the oracle."""
+    import threading
+    name, n, k = "full", 20011, 4
+    recs = synth.records(name, n, seed=23)
+    exp = c_walker.decode_threaded(recs, SCHEMAS[name], k)
+    res = _resident(recs)
+    d_data, d_off, dl = res
+    _call(res, n, SCHEMAS[name], k, asynchronous=False).free()
+    errors = []
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream(device="cuda:0")
+            ring = []
+            for i in range(12):
+                ring.append(cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), dl, n, SCHEMAS[name], k, device=0,
+                                               stream=st.cuda_stream, want_stats=False, asynchronous=True))
+                if len(ring) > 3:
+                    r = ring.pop(0)
+                    r.wait()
+                    if i % 4 == tid % 4:
+                        for g, e in zip(r.to_host(), exp):
+                            assert_batches_identical(g, e)
+                    r.free()
+            for r in ring:
+                for g, e in zip(r.to_host(), exp):          # settles inside the accessor
+                    assert_batches_identical(g, e)
+                r.free()
+        except Exception as e:                               # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
