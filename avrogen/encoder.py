@@ -38,6 +38,14 @@ class Unscaled:
 
 
 @dataclass
+class Dur:
+    """An Avro duration as written: months, days, milliseconds (three little-endian u32 on a fixed(12))."""
+    months: int
+    days: int
+    millis: int
+
+
+@dataclass
 class UuidText:
     """A uuid as the writer puts it on the wire: text for a string base, 16 raw bytes for a fixed(16) base."""
     text: object
@@ -70,6 +78,8 @@ def _fits(s: AvroSchema, v) -> bool:
         return isinstance(v, Unscaled)
     if k == "uuid":
         return isinstance(v, UuidText)
+    if k == "duration":
+        return isinstance(v, Dur)
     if k in ("float", "double"):
         return isinstance(v, float)
     if k in ("string", "enum"):
@@ -112,6 +122,8 @@ def encode(s: AvroSchema, v, out: bytearray) -> None:
             raw = (b"\xff" if u < 0 else b"\x00") * v.pad + raw
             out += zigzag(len(raw))
             out += raw
+    elif k == "duration":
+        out += struct.pack("<III", v.months, v.days, v.millis)
     elif k == "uuid":
         if s.items.kind == "fixed":
             assert isinstance(v.text, (bytes, bytearray)) and len(v.text) == 16

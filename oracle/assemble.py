@@ -60,7 +60,7 @@ def _validity(b: Buffers, always: bool):
 
 
 _NP = {
-    S.K_TIMEMILLI: np.int32, S.K_TIMEMICRO: np.int64,          # N4 (beyond the reference)
+    S.K_TIMEMILLI: np.int32, S.K_TIMEMICRO: np.int64, S.K_DURATION: np.int64,          # N4 (beyond the reference)
     S.K_INT: np.int32, S.K_DATE: np.int32,
     S.K_LONG: np.int64, S.K_TSMILLI: np.int64, S.K_TSMICRO: np.int64,
     S.K_FLOAT: np.uint32, S.K_DOUBLE: np.uint64,

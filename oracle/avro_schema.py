@@ -156,6 +156,10 @@ class _Parser:
                     if base.kind == "fixed" and base.size != 16:
                         return base
                     return AvroSchema(kind="uuid", items=base)
+                if lt == "duration":
+                    if base.size != 12:         # months / days / milliseconds, 4 bytes each: anything else stays a fixed
+                        return base
+                    return AvroSchema(kind="duration", items=base)
                 return AvroSchema(kind=lt)
             return base  # apache-avro warns and keeps the underlying type
         if isinstance(t, str):
@@ -288,7 +292,7 @@ def _is_supported_inner(s: AvroSchema, extra=frozenset()) -> bool:
 # unimplemented!()).  The GPU path decodes them; what "correct" means is therefore the Avro 1.11 specification,
 # restated in py_walker under `extended=True`.  PARITY UNPINNED BY THE REFERENCE for these types.
 # ---------------------------------------------------------------------------
-N4_LEAVES = {"bytes", "fixed", "decimal", "uuid", "time-millis", "time-micros"}
+N4_LEAVES = {"bytes", "fixed", "decimal", "uuid", "time-millis", "time-micros", "duration"}
 
 
 def is_supported_extended(s: AvroSchema) -> bool:
@@ -334,6 +338,8 @@ def _default_field_name(dt: pa.DataType) -> str:
         return "decimal"
     if pa.types.is_time(dt):
         return {"ms": "timemilli", "us": "timemicro"}[dt.unit]
+    if pa.types.is_duration(dt):
+        return "duration"               # schema_translate.rs:195
     if pa.types.is_list(dt):
         return "list"
     if pa.types.is_struct(dt):
@@ -404,6 +410,8 @@ def schema_to_field(s: AvroSchema, name: Optional[str], nullable: bool,
         dt = pa.time32("ms")
     elif k == "time-micros":                # :140
         dt = pa.time64("us")
+    elif k == "duration":               # :143
+        dt = pa.duration("ms")
     elif k == "array":
         dt = pa.list_(schema_to_field(s.items, "item", True, None))
     elif k == "map":
@@ -457,9 +465,9 @@ def to_arrow_schema(s: AvroSchema) -> pa.Schema:
 K_INT, K_LONG, K_FLOAT, K_DOUBLE, K_BOOL, K_STRING, K_DATE, K_TSMILLI, K_TSMICRO, K_ENUM, \
     K_NULL, K_RECORD, K_UNION, K_LIST, K_MAP = range(15)
 # N4 (beyond the reference; py_walker only): the wire forms of the Avro 1.11 specification
-K_BYTES, K_FIXED, K_DECIMAL, K_UUID, K_TIMEMILLI, K_TIMEMICRO = range(15, 21)
+K_BYTES, K_FIXED, K_DECIMAL, K_UUID, K_TIMEMILLI, K_TIMEMICRO, K_DURATION = range(15, 22)
 _N4_KIND = {"bytes": K_BYTES, "fixed": K_FIXED, "decimal": K_DECIMAL, "uuid": K_UUID,
-            "time-millis": K_TIMEMILLI, "time-micros": K_TIMEMICRO}
+            "time-millis": K_TIMEMILLI, "time-micros": K_TIMEMICRO, "duration": K_DURATION}
 
 _LEAF_KIND = {
     "int": K_INT, "long": K_LONG, "float": K_FLOAT, "double": K_DOUBLE, "boolean": K_BOOL,

@@ -143,8 +143,24 @@ def _n4_writer(s: S.AvroSchema, arr: pa.Array):
       decimal / fixed  the unscaled value as N big-endian bytes (its low N bytes: sign-extended when N > its width)
       uuid / string    varint 36 + lower-case 8-4-4-4-12 hex text of the 16 bytes
       uuid / fixed(16) the 16 bytes
-      time-millis / time-micros   zig-zag int / long"""
+      time-millis / time-micros   zig-zag int / long
+      duration         months = 0, days = min(v // 86 400 000, 2^32-1), milliseconds = the rest, three little-endian u32
+                       (a split py_walker's sum inverts for every value it produces); a negative count or one beyond
+                       2^32-1 days + 2^32-1 ms has no wire form"""
     k = s.kind
+    if k == "duration":
+        if arr.type != pa.duration("ms"):
+            raise EncodeError("fast_encode: arrow array downcast failed")
+        vals = _raw_values(arr, np.int64)
+
+        def wd(out, row):
+            v = int(vals[row])
+            days = min(v // 86_400_000, 0xFFFFFFFF)
+            ms = v - days * 86_400_000
+            if v < 0 or ms > 0xFFFFFFFF:
+                raise EncodeError(f"duration value at row {row} has no Avro duration form (negative, or beyond 2^32-1 days + 2^32-1 ms)")
+            out.extend((0).to_bytes(4, "little") + days.to_bytes(4, "little") + ms.to_bytes(4, "little"))
+        return wd
     if k in ("time-millis", "time-micros"):
         typ, dt = (pa.time32("ms"), np.int32) if k == "time-millis" else (pa.time64("us"), np.int64)
         if arr.type != typ:

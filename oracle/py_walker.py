@@ -163,7 +163,7 @@ class _B:
             self._append_value(read_bool(c))
         elif k == S.K_STRING:
             self._append_str(read_string(c))
-        elif k in (S.K_BYTES, S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO):
+        elif k in (S.K_BYTES, S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO, S.K_DURATION):
             self._decode_n4(c)
         elif k == S.K_ENUM:
             # append_enum, fast_decode.rs:570-578: `as usize` then symbols.get
@@ -194,6 +194,14 @@ class _B:
                 raw = read_string(c)
             if k == S.K_FIXED:
                 self._append_value(raw)
+            elif k == S.K_DURATION:
+                # Avro 1.11 "Duration": months, days, milliseconds as three little-endian u32.  The reference maps the
+                # type to Duration(Millisecond) (schema_translate.rs:143), ONE count of milliseconds: days and
+                # milliseconds add up to one; a months component has no length in milliseconds, so it is an error.
+                mo, dy, ms = (int.from_bytes(raw[i:i + 4], "little") for i in (0, 4, 8))
+                if mo != 0:
+                    raise DecodeError(f"duration with {mo} months has no value in Duration(ms)")
+                self._append_value(dy * 86_400_000 + ms)
             elif k == S.K_DECIMAL:               # big-endian two's complement unscaled value -> i128
                 if len(raw) > 16:
                     raise DecodeError(f"decimal value of {len(raw)} bytes does not fit Decimal128")
@@ -314,7 +322,7 @@ class _B:
         if k in (S.K_STRING, S.K_ENUM, S.K_BYTES):
             b.offsets = list(self.offsets)
             b.data = bytes(self.data)
-        if k in (S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO):
+        if k in (S.K_FIXED, S.K_DECIMAL, S.K_UUID, S.K_TIMEMILLI, S.K_TIMEMICRO, S.K_DURATION):
             b.values = list(self.values)
         if k in (S.K_LIST, S.K_MAP):
             b.offsets = list(self.offsets)

@@ -8,6 +8,7 @@ enum EncErr : uint32_t {
   EE_ENUM = 100,    // "fast_encode: enum symbol '{sym}' not in schema"   (fast_encode.rs:575-577); pad = op index, detail = row
   EE_DECIMAL = 102, // a Decimal128 value that is not an N-byte two's complement number on a fixed(N) base (ours: the reference
                     // does not encode decimals, fast_encode.rs:22); pad = N, detail = row
+  EE_DURATION = 103, // a Duration(ms) value below zero or beyond 2^32-1 days + 2^32-1 ms: no months/days/millis form (ours); detail = row
   EE_UNION = 101,   // "fast_encode: union type_id {t} out of range"      (fast_encode.rs:540-542); detail = t
 };
 

@@ -102,13 +102,15 @@ struct EInterp {
           break;
         }
 
-        case OP_BIN: {                        // fixed / decimal / uuid (encode_walk.h e_bin_put)
+        case OP_BIN: {                        // fixed / decimal / uuid / duration (encode_walk.h e_bin_put)
           if (wr) {
             BinV v;
             v.lo = 0; v.hi = 0;
             const uint32_t r = c.row(op.dom);
             v.valid = (op.flags & F_NULLABLE) ? c.bit(op.buf0, r) : true;
-            if (op.a != BN_FIXED && v.valid) {
+            if (op.a == BN_DURATION && v.valid) {             // Duration(ms): one i64 per row
+              v.lo = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1))[r];
+            } else if (op.a != BN_FIXED && v.valid) {
               const RH_GLOBAL u64u* p = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1)) + 2ull * r;
               v.lo = p[0]; v.hi = p[1];
             }

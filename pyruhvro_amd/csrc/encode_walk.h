@@ -242,7 +242,7 @@ __device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op) {
 }
 
 // SURVEY 8(f) N4 (beyond the reference, whose encoder gate is false for these types): fixed(N),
-// decimal and uuid leaves.  The 16 value bytes of a decimal / uuid row travel in registers; fixed(N) is copied from HBM.
+// decimal, uuid and duration leaves.  The 16 value bytes of a decimal / uuid row travel in registers; fixed(N) is copied from HBM.
 struct BinV { uint64_t lo, hi; bool valid; };
 
 template <class Ctx>
@@ -251,7 +251,9 @@ __device__ __forceinline__ BinV e_bin_load(const Ctx& c, const Op op) {
   BinV v;
   v.lo = 0; v.hi = 0;
   v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
-  if (op.a != BN_FIXED) {                                       // Decimal128 / FixedSizeBinary(16): 16 bytes per row
+  if (op.a == BN_DURATION) {                                    // Duration(ms): one i64 per row
+    v.lo = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1))[r];
+  } else if (op.a != BN_FIXED) {                                // Decimal128 / FixedSizeBinary(16): 16 bytes per row
     const RH_GLOBAL u64u* p = reinterpret_cast<const RH_GLOBAL u64u*>(c.in(op.buf1)) + 2ull * r;
     v.lo = p[0]; v.hi = p[1];
   }
@@ -276,6 +278,18 @@ __device__ __forceinline__ void e_bin_put(const Ctx& c, ELane& L, const Op op, c
   if (op.a == BN_FIXED) {
     const uint32_t W = (uint32_t)op.c;
     put_bytes<MODE>(c, L, reinterpret_cast<const RH_GLOBAL uint8_t*>(c.in(op.buf1)) + (uint64_t)c.row(op.dom) * W, W);
+  } else if (op.a == BN_DURATION) {
+    // months = 0, days = v / 86 400 000 (at most 2^32-1), milliseconds = the rest (three little-endian u32): the split
+    // h_bin's sum inverts, for every value it can produce.  A negative count, or one beyond 2^32-1 days + 2^32-1 ms, has
+    // no wire form.
+    uint64_t days = v.lo / 86400000ull;
+    days = days > 0xFFFFFFFFull ? 0xFFFFFFFFull : days;
+    const uint64_t ms = v.lo - days * 86400000ull;
+    if ((int64_t)v.lo < 0 || ms > 0xFFFFFFFFull) { L.err = EE_DURATION; L.eop = 0; L.edetail = c.row(op.dom); return; }
+    if (MODE == M_SIZE) { L.len += 12; return; }
+    put_raw<MODE, 4>(c, L, 0ull);
+    put_raw<MODE, 4>(c, L, days);
+    put_raw<MODE, 4>(c, L, ms);
   } else if (op.a == BN_DEC_FIXED) {
     const uint32_t N = (uint32_t)op.b;                          // <= 16 (schema gate)
     if (N < 16u) {      // the value must BE an N-byte two's complement number: bytes N..15 pure sign extension of byte N-1

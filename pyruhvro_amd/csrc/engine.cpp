@@ -389,6 +389,7 @@ std::string format_error(const rh::ErrInfo& e) {
     case rh::E_EOB_FIXED: return "unexpected end of buffer (fixed)";
     case rh::E_DECIMAL: std::snprintf(buf, sizeof buf, "decimal value of %lld bytes does not fit Decimal128", (long long)e.detail); return buf;
     case rh::E_UUID: return "invalid uuid string";
+    case rh::E_DURATION: std::snprintf(buf, sizeof buf, "duration with %lld months has no value in Duration(ms)", (long long)e.detail); return buf;
     default: return "decode error";
   }
 }
@@ -2271,8 +2272,9 @@ struct EncodeBinder {
         return;
       }
       case rh::NK_BIN: {              // FixedSizeBinary(N) / Decimal128 values, `bin_width` bytes per row
-        const std::string want = t->kind == rh::AV_DECIMAL ? "d:" + std::to_string(t->precision) + "," + std::to_string(t->scale)
-                                                           : "w:" + std::to_string(n.bin_width);
+        const std::string want = t->kind == rh::AV_DECIMAL    ? "d:" + std::to_string(t->precision) + "," + std::to_string(t->scale)
+                                 : t->kind == rh::AV_DURATION ? "tDm"
+                                                              : "w:" + std::to_string(n.bin_width);
         if (fmt != want || fa->n_buffers < 2 || (len > 0 && !fa->buffers[1])) throw EncodeError("fast_encode: arrow array downcast failed");
         InBuf& v = in[n.buf_main];
         v.host = len ? (const uint8_t*)fa->buffers[1] + (uint64_t)off * (uint64_t)n.bin_width : nullptr;
@@ -2384,7 +2386,7 @@ void release_binary(ArrowArray* a) {
 }
 
 std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, const EncodeBinder& b) {
-  char buf[96];
+  char buf[160];
   if (e.code == rh::EE_UNION) {
     std::snprintf(buf, sizeof buf, "fast_encode: union type_id %lld out of range", (long long)e.detail);
     return buf;
@@ -2406,6 +2408,10 @@ std::string format_encode_error(const rh::ErrInfo& e, const CompiledSchema& cs, 
   }
   if (e.code == rh::EE_DECIMAL) {
     std::snprintf(buf, sizeof buf, "decimal value at row %lld does not fit fixed(%u)", (long long)e.detail, e.pad);
+    return buf;
+  }
+  if (e.code == rh::EE_DURATION) {
+    std::snprintf(buf, sizeof buf, "duration value at row %lld has no Avro duration form (negative, or beyond 2^32-1 days + 2^32-1 ms)", (long long)e.detail);
     return buf;
   }
   std::snprintf(buf, sizeof buf, "encode error (code %u, op %u, detail %lld)", e.code, e.pad, (long long)e.detail);

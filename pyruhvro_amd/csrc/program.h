@@ -39,6 +39,7 @@ enum BinKind : int32_t {
   BN_DEC_BYTES = 1,  // decimal on bytes: length + big-endian two's complement -> Decimal128 (16 bytes, little-endian)
   BN_DEC_FIXED = 2,  // decimal on fixed(N <= 16): N bytes big-endian two's complement -> Decimal128
   BN_UUID_STR = 3,   // uuid on string: 36-char hyphenated (or 32-char simple) hex text -> FixedSizeBinary(16)
+  BN_DURATION = 4,   // duration on fixed(12): months / days / milliseconds, little-endian u32 each -> Duration(ms) (months must be 0)
 };
 
 enum OpCode : int32_t {
@@ -87,6 +88,7 @@ enum ErrCode : uint32_t {
   E_EOB_FIXED,    // N4 types (no reference message: the reference never decodes them)
   E_DECIMAL,      // a decimal of more than 16 bytes
   E_UUID,         // uuid text that is not 32 / 36 hex characters
+  E_DURATION,     // a duration with a non-zero months component: Duration(ms) has no value for it (detail = months)
 };
 
 struct ErrInfo {

@@ -139,7 +139,7 @@ struct Parser {
           {"local-timestamp-nanos", AV_OTHER_LOGICAL, AV_LONG, AV_LONG},
           {"uuid", AV_UUID, AV_STRING, AV_FIXED},
           {"decimal", AV_DECIMAL, AV_BYTES, AV_FIXED},
-          {"duration", AV_OTHER_LOGICAL, AV_FIXED, AV_FIXED},
+          {"duration", AV_DURATION, AV_FIXED, AV_FIXED},
       };
       for (auto& e : table) {
         if (lt->str != e.name) continue;
@@ -149,6 +149,7 @@ struct Parser {
           t->logical = e.name;
           t->size = base->kind == AV_FIXED ? base->size : -1;
           if (e.out == AV_UUID && base->kind == AV_FIXED && base->size != 16) return base;   // uuid needs 16 bytes
+          if (e.out == AV_DURATION && base->size != 12) return base;                         // duration is a fixed(12)
           if (e.out == AV_DECIMAL) {
             // precision is required and positive, scale defaults to 0 and must not exceed it, and a fixed base must be
             // able to hold the precision; anything else keeps the underlying type (apache-avro warns and does the same)
@@ -260,7 +261,7 @@ bool supported_inner(const AvroType& t, std::string& why) {
       return supported_inner(*t.items, why);
     // beyond the reference's gate (fast_decode.rs:59 sends these to a fallback whose column builder
     // answers unimplemented!(), complex.rs:414-431); decoded on the GPU from the Avro 1.11 wire rules
-    case AV_BYTES: case AV_TIME_MILLIS: case AV_TIME_MICROS: case AV_UUID:
+    case AV_BYTES: case AV_TIME_MILLIS: case AV_TIME_MICROS: case AV_UUID: case AV_DURATION:
       return true;
     case AV_FIXED:
       if (t.size > (1 << 20)) { why = "fixed of more than 1 MiB"; return false; }
@@ -293,6 +294,7 @@ const char* default_field_name(const std::string& fmt) {   // schema_translate.r
   if (fmt.rfind("d:", 0) == 0) return "decimal";
   if (fmt == "ttm") return "timemilli";
   if (fmt == "ttu") return "timemicro";
+  if (fmt == "tDm") return "duration";
   if (fmt == "+l") return "list";
   if (fmt == "+s") return "struct";
   if (fmt.rfind("+us:", 0) == 0) return "union";
@@ -345,6 +347,7 @@ ArrowField to_field(const AvroType& t, const std::string* name, bool nullable,
     case AV_UUID: f.format = "w:16"; break;                                         // :137
     case AV_TIME_MILLIS: f.format = "ttm"; break;                                   // :139
     case AV_TIME_MICROS: f.format = "ttu"; break;                                   // :140
+    case AV_DURATION: f.format = "tDm"; break;                                      // :143 Duration(Millisecond)
     case AV_ARRAY: {                                   // schema_translate.rs:60-65
       f.format = "+l";
       static const std::string item = "item";
@@ -455,6 +458,7 @@ struct Builder {
       case AV_DOUBLE: return 8;
       case AV_FIXED: return (uint32_t)t.size;
       case AV_DECIMAL: case AV_UUID: return t.size >= 0 ? (uint32_t)t.size : 1u;
+      case AV_DURATION: return 12;
       case AV_RECORD: {
         uint32_t s = 0;
         for (auto& f : t.fields) s += min_bytes(*f.type);
@@ -508,13 +512,14 @@ struct Builder {
   int build(const AvroType& t, bool nullable, bool null_first, Ctx cx) {
     if (cx.nest > kMaxNest) throw SchemaError("schema nesting too deep for the GPU decoder");
     switch (t.kind) {
-      case AV_FIXED: case AV_DECIMAL: case AV_UUID: {
+      case AV_FIXED: case AV_DECIMAL: case AV_UUID: case AV_DURATION: {
         int id = new_node(NK_BIN);
         const int32_t sub = t.kind == AV_FIXED ? BN_FIXED
+                            : t.kind == AV_DURATION ? BN_DURATION
                             : t.kind == AV_DECIMAL ? (t.size >= 0 ? BN_DEC_FIXED : BN_DEC_BYTES)
                             : (t.size >= 0 ? BN_FIXED : BN_UUID_STR);
         const int32_t wire = t.size >= 0 ? (int32_t)t.size : 0;
-        const int32_t width = t.kind == AV_FIXED ? (int32_t)t.size : 16;
+        const int32_t width = t.kind == AV_FIXED ? (int32_t)t.size : t.kind == AV_DURATION ? 8 : 16;
         {
           DecNode& n = cs.nodes[id];
           n.nullable = nullable; n.null_first = null_first; n.dom = cx.dom;

@@ -26,8 +26,8 @@ enum AvroKind {
   AV_NULL, AV_BOOLEAN, AV_INT, AV_LONG, AV_FLOAT, AV_DOUBLE, AV_BYTES, AV_STRING,
   AV_RECORD, AV_ENUM, AV_ARRAY, AV_MAP, AV_UNION, AV_FIXED,
   AV_DATE, AV_TS_MILLIS, AV_TS_MICROS,
-  AV_TIME_MILLIS, AV_TIME_MICROS, AV_DECIMAL, AV_UUID,   // SURVEY 8f N4 (with AV_BYTES / AV_FIXED)
-  AV_OTHER_LOGICAL,   // duration, local-timestamp-*, timestamp-nanos (no Arrow mapping in the reference: schema_translate.rs:144)
+  AV_TIME_MILLIS, AV_TIME_MICROS, AV_DECIMAL, AV_UUID, AV_DURATION,   // SURVEY 8f N4 (with AV_BYTES / AV_FIXED)
+  AV_OTHER_LOGICAL,   // local-timestamp-*, timestamp-nanos (no Arrow mapping in the reference: schema_translate.rs:144)
   AV_REF,
 };
 

@@ -629,6 +629,21 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
         lo = (lo << 8) | b;
       }
     }
+  } else if (op.a == BN_DURATION) {
+    // months / days / milliseconds, three little-endian u32.  Arrow's Duration(ms) (the reference's mapping,
+    // schema_translate.rs:143) is ONE count of milliseconds: days x 86 400 000 + milliseconds; a months component has no
+    // value in it, so a duration that carries one is a decode error (found by the size pass, like every other)
+    uint32_t mo = 0, dy = 0, ms = 0;
+    if (valid) {
+      for (uint32_t j = 0; j < 4; j++) {
+        if constexpr (!RH_TRUST) mo |= src.ld1(spos + j) << (8 * j);
+        dy |= src.ld1(spos + 4 + j) << (8 * j);
+        ms |= src.ld1(spos + 8 + j) << (8 * j);
+      }
+    }
+    RH_REJECT(L, valid && mo != 0, E_DURATION, (int64_t)mo);
+    valid = valid && L.live;
+    lo = (uint64_t)dy * 86400000ull + (uint64_t)ms;
   } else if (op.a == BN_UUID_STR) {
     bool badtxt = false;
     if (valid) {
@@ -661,7 +676,7 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
       } else {
         if (!valid) { lo = 0; hi = 0; }
         st_at<u64u, Ctx::kWide>(c.buf(op.buf1), off, lo);
-        st_at<u64u, Ctx::kWide>(c.buf(op.buf1), off + 8, hi);
+        if (W > 8) st_at<u64u, Ctx::kWide>(c.buf(op.buf1), off + 8, hi);       // (Duration(ms): 8 bytes per row)
       }
     }
   }

@@ -35,6 +35,7 @@ def known_schemas() -> List[str]:
         out += [random_cases.random_schema(seed) for seed in range(random_cases.PREBUILT_SEEDS)]
         import test_n4_types                      # SURVEY 8f N4 schemas
         out.append(test_n4_types.SCHEMA)
+        out.append(test_n4_types.DUR_SCHEMA)
         import test_named_refs                    # named-type references (resolved by the front-end)
         out.append(test_named_refs.WITH_REFS)
         g = json.load(open(os.path.join(root, "tests", "golden", "reference_vectors.json")))

@@ -59,7 +59,6 @@ def test_arrow_schema_nesting_cases_and_metadata():
 BAD_SCHEMAS = [
     ("not json", "Failed to parse schema"),
     ('"string"', "record"),
-    ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f","size":12,"logicalType":"duration"}}]}', "duration"),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"long","logicalType":"local-timestamp-millis"}}]}', "local-timestamp-millis"),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"long","logicalType":"timestamp-nanos"}}]}', "timestamp-nanos"),
     ('{"type":"record","name":"x","fields":[{"name":"a","type":{"type":"fixed","name":"f"}}]}', "size"),

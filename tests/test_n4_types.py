@@ -1,4 +1,4 @@
-"""bytes, fixed, decimal, uuid, time-millis, time-micros on the GPU decode path.
+"""bytes, fixed, decimal, uuid, time-millis, time-micros, duration on the GPU decode path.
 
 The reference TRANSLATES these schemas to Arrow (schema_translate.rs:58,133-140 -- restated in the oracle and matched
 by the product, tested here) but never DECODES them: its direct path rejects them (fast_decode.rs:59) and the
@@ -14,7 +14,7 @@ import pyarrow as pa
 import pytest
 
 from arrow_compare import assert_batches_identical
-from avrogen.encoder import Branch, Unscaled, UuidText, to_datum, zigzag
+from avrogen.encoder import Branch, Dur, Unscaled, UuidText, to_datum, zigzag
 from oracle import avro_schema as S
 from oracle import py_encoder, py_walker
 
@@ -272,3 +272,108 @@ def test_gpu_encode_refuses_a_decimal_that_does_not_fit_its_fixed(kernel):
         with pytest.raises(ValueError) as ei:
             P.serialize_record_batch(raw(vals), js, 2)
         assert str(ei.value) == "decimal value at row %d does not fit fixed(2)" % bad_row
+
+
+# ---------------------------------------------------------------------------------------------------- duration
+# Avro 1.11 "Duration": a fixed(12) of months, days, milliseconds (three little-endian u32).  The reference maps it to
+# Duration(Millisecond) (schema_translate.rs:143), one i64 count of milliseconds: days x 86 400 000 + milliseconds is the
+# only reading of that; a months component has no length in milliseconds, so a datum that carries one is a decode error.
+DAY = 86_400_000
+DUR = F("Dur", 12, logicalType="duration")
+DUR_SCHEMA = json.dumps({"type": "record", "name": "D", "fields": [
+    {"name": "d", "type": DUR},
+    {"name": "nd", "type": ["null", F("Dur2", 12, logicalType="duration")]},
+    {"name": "arr", "type": {"type": "array", "items": F("Dur3", 12, logicalType="duration")}},
+    {"name": "un", "type": ["null", "string", F("Dur4", 12, logicalType="duration"), "long"]},
+    {"name": "m", "type": {"type": "map", "values": [F("Dur5", 12, logicalType="duration"), "null"]}},
+    {"name": "tail", "type": "string"},
+]})
+
+
+def _dur_rows(n):
+    return [{"d": Dur(0, i, (i * 7919) % (1 << 32)), "nd": None if i % 3 == 0 else Dur(0, (i * 65537) % (1 << 32), 0xFFFFFFFF - i),
+             "arr": [Dur(0, j, i) for j in range(i % 5)],
+             "un": [None, f"s{i}", Branch(2, Dur(0, 0xFFFFFFFF, 0xFFFFFFFF)), i][i % 4],
+             "m": [(f"k{j}", None if (i + j) % 2 else Dur(0, 1, j)) for j in range(i % 3)],
+             "tail": f"t{i}"} for i in range(n)]
+
+
+def _dur_records(n):
+    sc = S.parse_schema(DUR_SCHEMA)
+    return [to_datum(sc, r) for r in _dur_rows(n)]
+
+
+def test_duration_translation_and_known_answers():
+    js = '{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}'
+    avro = S.parse_schema(js % json.dumps(DUR))
+    assert not S.is_supported(avro) and S.is_supported_extended(avro)
+    assert P.arrow_schema(js % json.dumps(DUR)).field("a").type == pa.duration("ms") == S.to_arrow_schema(avro).field("a").type
+    got = P.arrow_schema(DUR_SCHEMA)
+    assert got.equals(S.to_arrow_schema(S.parse_schema(DUR_SCHEMA)), check_metadata=True)
+    assert [c.name for c in got.field("un").type] == ["null", "varchar", "duration", "bigint"]      # schema_translate.rs:195
+    # a duration is a fixed(12); on any other size the attribute is ignored and the fixed stays (as for uuid on fixed(8))
+    odd = js % json.dumps(F("q", 11, logicalType="duration"))
+    assert P.arrow_schema(odd).field("a").type == pa.binary(11) == S.to_arrow_schema(S.parse_schema(odd)).field("a").type
+    recs = [bytes.fromhex("00000000" "01000000" "02000000"), bytes.fromhex("00000000" "ffffffff" "ffffffff"), bytes(12),
+            bytes.fromhex("00000000" "00000000" "00005265")]                 # 0x65520000 ms = 1 700 003 840: more than a day, kept as is
+    rows = py_walker.decode(recs, js % json.dumps(DUR), extended=True).column("a").cast(pa.int64()).to_pylist()
+    assert rows == [DAY + 2, 0xFFFFFFFF * DAY + 0xFFFFFFFF, 0, 0x65520000]
+    with pytest.raises(ValueError, match="duration with 3 months has no value in Duration\\(ms\\)"):
+        py_walker.decode([bytes.fromhex("03000000" "01000000" "02000000")], js % json.dumps(DUR), extended=True)
+    with pytest.raises(ValueError, match="unexpected end of buffer \\(fixed\\)"):
+        py_walker.decode([bytes(11)], js % json.dumps(DUR), extended=True)
+    # the encoder writes months = 0 and the days / milliseconds split the decoder's sum inverts
+    rb = pa.RecordBatch.from_arrays([pa.array([DAY + 2, 0, DAY - 1, 0xFFFFFFFF * DAY + DAY - 1, 0xFFFFFFFF * DAY + 0xFFFFFFFF], pa.duration("ms"))], names=["a"])
+    out = [x for a in py_encoder.serialize_record_batch(rb, js % json.dumps(DUR), 1, extended=True) for x in a.to_pylist()]
+    assert out == [bytes.fromhex("00000000" "01000000" "02000000"), bytes(12), bytes.fromhex("00000000" "00000000" "ff5b2605"),
+                   bytes.fromhex("00000000" "ffffffff" "ff5b2605"), bytes.fromhex("00000000" "ffffffff" "ffffffff")]
+    for bad in (-1, 0xFFFFFFFF * DAY + (1 << 32)):
+        with pytest.raises(ValueError, match="no Avro duration form"):
+            py_encoder.serialize_record_batch(pa.RecordBatch.from_arrays([pa.array([0, bad], pa.duration("ms"))], names=["a"]),
+                                              js % json.dumps(DUR), 1, extended=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1, 1), (300, 3), (2500, 8)])
+def test_gpu_duration_both_directions(n, k, kernel):
+    recs = _dur_records(n)
+    whole = py_walker.decode(recs, DUR_SCHEMA, extended=True)
+    got = P.deserialize_array_threaded(recs, DUR_SCHEMA, k)
+    sz = n // min(k, n)
+    for i, g in enumerate(got):
+        g.validate(full=True)
+        assert_batches_identical(g, py_walker.decode(recs[i * sz: i * sz + g.num_rows], DUR_SCHEMA, extended=True))
+    assert pa.Table.from_batches(got).combine_chunks().equals(pa.Table.from_batches([whole]))     # (to_pylist: timedelta cannot hold 2^32 days)
+    enc = P.serialize_record_batch(whole, DUR_SCHEMA, k)
+    for g, e in zip(enc, py_encoder.serialize_record_batch(whole, DUR_SCHEMA, k, extended=True)):
+        assert g.equals(e)
+    datums = [x for a in enc for x in a.to_pylist()]
+    assert_batches_identical(P.deserialize_array(datums, DUR_SCHEMA), whole)
+    # days and milliseconds are folded into one count: a datum with more than a day of milliseconds comes back normalised
+    assert sum(a == b for a, b in zip(datums, recs)) < n or n == 1
+
+
+@pytest.mark.gpu
+def test_gpu_duration_errors(kernel):
+    js = json.dumps({"type": "record", "name": "x", "fields": [{"name": "s", "type": "string"}, {"name": "a", "type": ["null", DUR]}]})
+    good = b"\x02g" + b"\x02" + bytes.fromhex("00000000" "01000000" "02000000")
+    assert P.deserialize_array([good] * 3, js).column("a").cast(pa.int64()).to_pylist() == [DAY + 2] * 3
+    for bad, msg in ((b"\x02g" + b"\x02" + bytes.fromhex("07000000" "01000000" "02000000"), "duration with 7 months has no value in Duration(ms)"),
+                     (b"\x02g" + b"\x02" + bytes.fromhex("00000001" "01000000" "02000000"), "duration with 16777216 months has no value in Duration(ms)"),
+                     (b"\x02g" + b"\x02" + bytes(11), "unexpected end of buffer (fixed)")):
+        for recs in ([bad], [good] * 300 + [bad] + [good] * 5):
+            with pytest.raises(ValueError) as ei:
+                P.deserialize_array_threaded(recs, js, 2)
+            assert str(ei.value) == msg
+            with pytest.raises(ValueError) as eo:
+                py_walker.decode(recs, js, extended=True)
+            assert str(eo.value) == msg
+    one = '{"type":"record","name":"x","fields":[{"name":"a","type":%s}]}' % json.dumps(DUR)
+    for bad_row, bad in ((1, -1), (0, 0xFFFFFFFF * DAY + (1 << 32)), (2, -(1 << 62))):
+        vals = [5, 6, 7, -9]
+        vals[bad_row] = bad
+        with pytest.raises(ValueError) as ei:
+            P.serialize_record_batch(pa.RecordBatch.from_arrays([pa.array(vals, pa.duration("ms"))], names=["a"]), one, 2)
+        assert str(ei.value) == "duration value at row %d has no Avro duration form (negative, or beyond 2^32-1 days + 2^32-1 ms)" % bad_row
+    with pytest.raises(ValueError, match="arrow array downcast failed"):
+        P.serialize_record_batch(pa.RecordBatch.from_arrays([pa.array([1], pa.duration("us"))], names=["a"]), one, 1)

@@ -52,7 +52,7 @@ def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
                                    '{"name":"f","type":{"type":"fixed","name":"f7","size":7}}]}')
     assert "e_string_put_cf<MODE>" in n4 and "e_bin_load(c, op" in n4 and "e_bin_put<MODE>" in n4
     with pytest.raises(ValueError):
-        cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"fixed","name":"d","size":12,"logicalType":"duration"}}]}')
+        cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"long","logicalType":"timestamp-nanos"}}]}')
 
 
 def test_unsupported_schema_has_no_kernel():
