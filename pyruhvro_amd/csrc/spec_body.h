@@ -278,7 +278,10 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
 template <class S, bool EMIT, bool CAREFUL>
 __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
-    LdsSrc src{win};
+    // cursors become LDS byte addresses (walk.h LdsAbsSrc: k_emit -3 %, profiles/r03ap_abs_window_ab.txt)
+    const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)win;
+    L.cur += wa; L.end += wa;
+    LdsAbsSrc src;
     S::template walk<EMIT, CAREFUL>(c, src, L);
   } else {
     GlobalSrc src{P.data + wb16, P.data_len - wb16};

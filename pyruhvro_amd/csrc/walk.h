@@ -101,6 +101,49 @@ struct LdsSrc {
   }
 };
 
+// The same window, addressed ABSOLUTELY: positions are LDS byte addresses (the window's own LDS address is added to
+// the cursors once, when a lane starts).  The address of dynamic LDS is only known to the backend after instruction
+// selection, so `window + position` costs every read two VALU adds (`+ 0` for the symbol, `+ the window's offset`, too
+// large for the offset field of ds_read2_b32) that an absolute position does not need: ~8 % of the size walk's VALU.
+#ifndef RH_LDS
+#define RH_LDS __attribute__((address_space(3)))
+#endif
+struct LdsAbsSrc {
+  static __device__ __forceinline__ const RH_LDS uint32_t* dw(uint32_t p) { return reinterpret_cast<const RH_LDS uint32_t*>((uintptr_t)(p & ~3u)); }
+  __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return *reinterpret_cast<const RH_LDS uint8_t*>((uintptr_t)p); }
+  __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
+    const RH_LDS uint32_t* a = dw(p);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ v4w ld16(uint32_t p) const {
+    const RH_LDS uint32_t* a = dw(p);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+    const uint32_t sh = p & 3u;
+    v4w r;
+    r.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    r.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    r.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    return r;
+  }
+  __device__ __forceinline__ uint32_t ld4(uint32_t p) const {
+    const RH_LDS uint32_t* a = dw(p);
+    return __builtin_amdgcn_alignbyte(a[1], a[0], p & 3u);
+  }
+  __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
+    const RH_LDS uint32_t* a = dw(p);
+    const uint32_t d0 = a[0], d1 = a[1];
+    const uint32_t sh = p & 3u;
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
+  }
+};
+
 struct GlobalSrc {
   const uint8_t* g;   // payload + window base
   uint64_t lim;       // readable bytes from g
