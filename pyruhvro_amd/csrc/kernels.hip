@@ -36,6 +36,8 @@ namespace rh {
 struct ICtx {
   static constexpr bool kWide = true;   // 64-bit buffer indexing: any chunk size
   static constexpr bool kSkip = false;
+  static constexpr bool kEnumImm = false;
+  static __device__ __forceinline__ bool enum_sym(int, uint32_t, uint32_t&, uint64_t&) { return false; }
   uint32_t* cnt;             // LDS [K][256]
   uint32_t* rem;             // LDS [depth][256]
   uint32_t* nullcnt;         // LDS [nnodes]

@@ -84,6 +84,8 @@ struct SCtx {
   __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufp[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
+  static constexpr bool kEnumImm = true;              // enum symbols as immediates where the schema allows (Spec::enum_sym)
+  static __device__ __forceinline__ bool enum_sym(int b, uint32_t v, uint32_t& len, uint64_t& bits) { return S::enum_sym(b, v, len, bits); }
   // no per-node accumulators (NNODES wave-uniform registers that spill): one LDS add per field and wave
   // (k_emit 0.950 -> 0.937 ms, profiles/r02a_variants_ab.txt)
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {

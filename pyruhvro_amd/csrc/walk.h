@@ -251,6 +251,15 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
   }
 }
 
+// the low `len` (1..8) bytes of a register -> d, exactly (neighbouring lanes own the neighbouring bytes)
+template <bool WIDE>
+__device__ __forceinline__ void store_reg8(void* base, typename BufOff<WIDE>::type d, uint64_t x, uint32_t len) {
+  if (len & 8u) { st_at<u64u, WIDE>(base, d, x); return; }
+  if (len & 4u) st_at<u32u, WIDE>(base, d, (uint32_t)x);
+  if (len & 2u) st_at<u16u, WIDE>(base, d + (len & 4u), (uint16_t)(x >> (8 * (len & 4u))));
+  if (len & 1u) st_at<uint8_t, WIDE>(base, d + (len & 6u), (uint8_t)(x >> (8 * (len & 6u))));
+}
+
 template <class D>
 __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len) {
   for (uint32_t j = 0; j < len; j++) d[j] = s[j];
@@ -480,6 +489,8 @@ template <class C>
 struct SkipCtx {
   static constexpr bool kSkip = true;
   static constexpr bool kWide = C::kWide;
+  static constexpr bool kEnumImm = C::kEnumImm;
+  static __device__ __forceinline__ bool enum_sym(int b, uint32_t v, uint32_t& len, uint64_t& bits) { return C::enum_sym(b, v, len, bits); }
   const C& base;
   const uint32_t* sym_off;
   const uint8_t* sym_data;
@@ -524,6 +535,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
   const bool dec = act && L.pres;
   const bool is_int = op.a == FK_I32 || op.a == FK_I64;
   int64_t v = 0;
+  void* const pf1 = (EMIT && op.a != FK_BOOL) ? c.buf(op.buf1) : nullptr;     // requested ahead of the head: see h_string
   const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
                                         op.a == FK_I64, v);
   uint64_t bits;
@@ -556,8 +568,8 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
         c.set_bit(op.buf1, op.dom, row);
       }
     } else if (act) {
-      if (op.a == FK_I32 || op.a == FK_F32) st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row, (uint32_t)bits);
-      else st_global<uint64_t, Ctx::kWide>(c.buf(op.buf1), row, bits);
+      if (op.a == FK_I32 || op.a == FK_F32) st_global<uint32_t, Ctx::kWide>(pf1, row, (uint32_t)bits);
+      else st_global<uint64_t, Ctx::kWide>(pf1, row, bits);
     }
   }
   put_validity<EMIT>(c, op, act, valid, row);
@@ -569,9 +581,15 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   const bool act = L.live;
   const bool dec = act && L.pres;
   int64_t v = 0;
+  // The buffer addresses (scalar loads through the constant cache) are requested before the head is read, so their
+  // latency runs beside the LDS read instead of in front of each store (k_emit -1.2 %, profiles/r03at_variants_ab.txt)
+  void* const pb1 = EMIT ? c.buf(op.buf1) : nullptr;
+  void* const pb2 = EMIT ? c.buf(op.buf2) : nullptr;
   const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, true);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
+  bool sym_imm = false;
+  uint64_t sym_bits = 0;
   if (op.code == OP_STRING) {
     // the fast walk only ever sees lengths from the 28-bit single-read decode: 32-bit compares are enough there
     const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
@@ -584,7 +602,15 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   } else {
     const bool oor = want && (CAREFUL ? (uint64_t)v >= (uint64_t)op.c : (uint32_t)v >= (uint32_t)op.c);
     RH_REJECT(L, oor, E_ENUM, v);
-    if (want && L.live) {
+    // few, short symbols: (length, bytes) selected from immediates by the index.  Only where the length is all that is
+    // needed (the size pass: k_size -1.2 %); the emit walk is 2.2 % SLOWER with the immediates than with its two trips
+    // to memory (three A/B pairs, profiles/r03au_enum_immediates_ab.txt)
+    if constexpr (Ctx::kEnumImm && !EMIT) {
+      uint32_t l0 = 0;
+      sym_imm = c.enum_sym(op.b, (uint32_t)v, l0, sym_bits);
+      if (sym_imm) len = (want && L.live) ? l0 : 0u;
+    }
+    if (!sym_imm && want && L.live) {
       spos = c.sym_off[op.b + (int32_t)v];
       len = c.sym_off[op.b + (int32_t)v + 1] - spos;
     }
@@ -597,17 +623,21 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
     row = row_of(c, op.dom);
     if (act) {
       const uint32_t gb = c.gbase(op.a);
-      st_global<uint32_t, Ctx::kWide>(c.buf(op.buf1), row + 1, gb + o + len);   // offsets repeat under nulls
+      st_global<uint32_t, Ctx::kWide>(pb1, row + 1, gb + o + len);   // offsets repeat under nulls
       if (len) {
         // String bytes go straight to HBM with per-lane 8-byte stores at any alignment: neighbouring lanes
         // own neighbouring rows, so one wave store covers one contiguous span of the column.  (Staging the
         // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
         // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
         if (op.code == OP_STRING) {
-          copy_bytes<Ctx::kWide>(c.buf(op.buf2), (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
+          copy_bytes<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
         } else {
-          RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(c.buf(op.buf2))) + gb + o;
-          copy_plain(d, c.sym_data + spos, len);
+          if (sym_imm) {
+            store_reg8<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, sym_bits, len);
+          } else {
+            RH_GLOBAL uint8_t* d = reinterpret_cast<RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(pb2)) + gb + o;
+            copy_plain(d, c.sym_data + spos, len);
+          }
         }
       }
     }
@@ -751,12 +781,13 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   L.sstk = (L.sstk << 8) | 0xFFull;
   const bool dec = act && L.pres;
   int64_t idx = 0;
+  void* const pu1 = EMIT ? c.buf(op.buf1) : nullptr;           // requested ahead of the head: see h_string
   const bool got = read_head<CAREFUL, RH_TRUST>(src, L, dec, false, false, true, false, idx, true) && L.live;
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
   if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
-  if (EMIT && act) st_global<int8_t, Ctx::kWide>(c.buf(op.buf1), row_of(c, op.dom), (int8_t)tidv);
+  if (EMIT && act) st_global<int8_t, Ctx::kWide>(pu1, row_of(c, op.dom), (int8_t)tidv);
 }
 __device__ __forceinline__ void h_variant(Lane& L, const Op& op) {
   L.pres = (L.pstk & 1) && ((uint32_t)(L.sstk & 0xFF) == (uint32_t)op.a);

@@ -303,6 +303,29 @@ def long_string_case(n=1500, seed=5):
     return s, _enc(s, vals)
 
 
+def enum_form_cases():
+    """Enums on both sides of the specialised kernels' symbols-as-immediates rule (specialize.cpp Spec::enum_sym: at most 16
+    symbols of at most 8 bytes get their length from a select chain in the size pass; anything else reads the symbol
+    table): lengths 1..8 mixed, exactly 16 and 17 symbols, a 9-byte symbol, nullable / in a list / in a union.
+    -> list of (name, schema_json, records)."""
+    sy8 = ["a", "bb", "ccc", "dddd", "eeeee", "ffffff", "ggggggg", "hhhhhhhh"]
+    sy16 = [f"S{i:02d}" for i in range(16)]
+    sy17 = [f"T{i}" for i in range(17)]
+    sy9 = ["short", "ninebytes", "x"]
+    s = json.dumps({"type": "record", "name": "EF", "fields": [
+        {"name": "e8", "type": {"type": "enum", "name": "E8", "symbols": sy8}},
+        {"name": "e16", "type": ["null", {"type": "enum", "name": "E16", "symbols": sy16}]},
+        {"name": "e17", "type": {"type": "enum", "name": "E17", "symbols": sy17}},
+        {"name": "e9", "type": {"type": "array", "items": {"type": "enum", "name": "E9", "symbols": sy9}}},
+        {"name": "u", "type": ["null", "int", {"type": "enum", "name": "EU", "symbols": ["only"]}]},
+        {"name": "l8", "type": {"type": "array", "items": {"type": "enum", "name": "E8b", "symbols": sy8[::-1]}}},
+        {"name": "tail", "type": "string"}]})
+    vals = [{"e8": sy8[i % 8], "e16": None if i % 5 == 0 else sy16[(i * 7) % 16], "e17": sy17[(i * 3) % 17],
+             "e9": [sy9[(i + j) % 3] for j in range(i % 4)], "u": [None, i, "only"][i % 3],
+             "l8": [sy8[(i * j) % 8] for j in range(i % 6)], "tail": f"t{i}"} for i in range(700)]
+    return [("enum_forms", s, _enc(s, vals))]
+
+
 def dense_list_cases():
     """Top-level arrays / maps in the shapes the specialised emit kernel handles one lane per ITEM (spec_body.h
     dense_list): every body kind, more items per wavefront than its position table holds (several rounds), one huge list

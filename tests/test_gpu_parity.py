@@ -96,6 +96,17 @@ def test_wire_forms_and_nesting(case):
     _check((recs * 40)[:1000], schema, 7)
 
 
+@pytest.mark.parametrize("case", cases.enum_form_cases(), ids=lambda c: c[0])
+def test_enum_symbol_forms(case):
+    """Symbols as immediates in the specialised size pass (<= 16 symbols of <= 8 bytes) and the symbol-table path beside
+    it (17 symbols, a 9-byte symbol), top level / nullable / list items / union variant: both kernel forms, buffer for
+    buffer against the oracle."""
+    name, schema, recs = case
+    for k in (1, 3, 8):
+        _check(recs, schema, k)
+    _check((recs * 2)[5:], schema, 4)
+
+
 @pytest.mark.parametrize("case", cases.dense_list_cases(), ids=lambda c: c[0])
 def test_item_dense_lists(case):
     """The specialised emit kernel materialises top-level arrays / maps one lane per ITEM (spec_body.h dense_list):
