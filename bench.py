@@ -213,14 +213,14 @@ def run(args, make_step=None, backend="nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        rdist.init_process_group(backend)
     use_cuda = backend == "nccl"
     if use_cuda:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device("cpu")
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # (BENCH_FORCE_DIST: a one-rank RCCL group, to test the plumbing on one GPU)
+        rdist.init_process_group(backend, dev if use_cuda else None)
 
     gen_cfg, n, num_chunks, desc = WORKLOADS[args.workload]
     if args.records:
@@ -235,7 +235,7 @@ def run(args, make_step=None, backend="nccl"):
 
     def sync():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if use_cuda else dist.barrier()
         if use_cuda:
             torch.cuda.synchronize()
 
@@ -663,9 +663,10 @@ def main(argv=None):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     rank, world, wall, per_rank, agg, (gen_cfg, n, num_chunks, desc) = run(args, gpu_step_factory, "nccl")
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if world > 1:
+            dist.barrier(device_ids=[int(os.environ.get("LOCAL_RANK", "0"))])
         dist.destroy_process_group()          # clean teardown of the RCCL communicator on every rank
     if rank != 0:
         return

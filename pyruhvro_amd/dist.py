@@ -44,10 +44,15 @@ def partition_chunks(n: int, num_chunks: int, world: int) -> List[List[Tuple[int
     return out
 
 
-def init_process_group(backend: str):
+def init_process_group(backend: str, device=None):
+    """`device`: this rank's GPU (backend "nccl" = RCCL): handed to torch so the communicator is bound to it from the
+    start and barriers do not have to guess the device."""
     import torch.distributed as dist
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
+        if device is not None and backend == "nccl":
+            dist.init_process_group(backend=backend, device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
 
