@@ -331,6 +331,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   RH_MARK(17);
   spec_run_walk<S, false, false>(P, c, s.win, L, fits, wb16);
   bool careful = !fits;
+  L.redo = L.redo || L.cur > L.end;      // the one bounds check of the fast walk (walk.h read_head): a cursor past its record's end
   if (__any(L.redo)) {   // some record of this wave left the fast wire forms (or is malformed): walk the wave again, carefully
     careful = true;
     spec_ctx_init(c, P, s, g, tid);

@@ -413,7 +413,12 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   if (!nullable && !want_varint) return dec;
   const bool narrow = kNarrow && small && !wide;      // `small`: a length / index / count (see varint16)
   const uint64_t x = (want_varint && wide) ? src.ld8(L.cur) : (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
-  const uint32_t avail = L.end - L.cur;
+  // The fast size walk (neither careful nor trusted) checks a record's bounds ONCE, at its end (spec_size: cursor past
+  // the record's end -> the wave is walked again, carefully): a cursor only ever moves forward, so a read that runs past
+  // the end leaves it past the end for good, and what such a lane decodes meanwhile is never used.  No compare against
+  // the bytes left per head (k_size -6...-9 %, profiles/r03bb_deferred_bounds_ab.txt).  List block headers keep theirs
+  // (h_list_next): they are what bounds the work of a lane that has lost its record.
+  const uint32_t avail = (!CAREFUL && !TRUST) ? 0x7FFFFFFFu : L.end - L.cur;
   uint32_t skip = 0;
   bool okb = true, isval = dec;
   uint64_t y = x;
@@ -548,7 +553,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     const uint32_t avail = L.end - L.cur;
     const uint32_t need = op.a == FK_F32 ? 4u : op.a == FK_F64 ? 8u : 1u;
     const bool want = isval && L.live;
-    const bool eob = want && avail < need;
+    const bool eob = (!CAREFUL && !RH_TRUST) ? false : (want && avail < need);      // (fast size walk: see read_head)
     bits = op.a == FK_F32 ? (uint64_t)(uint32_t)x : op.a == FK_F64 ? x : (x & 0xFFu);
     const bool badb = want && !eob && op.a == FK_BOOL && bits > 1;   // read_bool, 893-900
     RH_REJECT(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
@@ -593,7 +598,8 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   if (op.code == OP_STRING) {
     // the fast walk only ever sees lengths from the 28-bit single-read decode: 32-bit compares are enough there
     const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
-    const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur);
+    // (the fast size walk checks a record's bounds once, at its end: see read_head)
+    const bool eob = (!CAREFUL && !RH_TRUST) ? false : (want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur));
     RH_REJECT(L, neg, E_NEGLEN);
     RH_REJECT(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
@@ -865,7 +871,11 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
   // common wire form: a small positive count, or the 0 terminator, in one byte..four bytes
   const uint32_t x = kNarrow ? src.ld4(L.cur) : (uint32_t)src.ld5(L.cur);
   uint32_t raw, n;
-  const bool okv = kNarrow ? varint16(x, L.end - L.cur, raw, n) : varint32(x, L.end - L.cur, raw, n);
+  // bytes left, 0 for a cursor that is already past its record's end (only the fast walk can be: read_head): such a
+  // lane fails here, so a garbage block count never starts a loop
+  const int32_t left = (int32_t)(L.end - L.cur);
+  const uint32_t lav = CAREFUL ? (uint32_t)left : (uint32_t)(left < 0 ? 0 : left);
+  const bool okv = kNarrow ? varint16(x, lav, raw, n) : varint32(x, lav, raw, n);
   const bool fast = need && okv && (raw & 1u) == 0 && (op.buf2 > 0 || raw == 0);   // non-negative; zero-width items take the exact path
   const bool slow = need && !fast;
   if (fast) {
@@ -873,7 +883,7 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
     L.cur += n;
     if (cnt == 0) L.live = false;
     else {
-      const uint32_t cap = (L.end - L.cur) / (uint32_t)(op.buf2 > 0 ? op.buf2 : 1) + 1;
+      const uint32_t cap = (lav - n) / (uint32_t)(op.buf2 > 0 ? op.buf2 : 1) + 1;
       rm = cnt < cap ? cnt : cap;
     }
   }
