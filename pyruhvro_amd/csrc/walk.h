@@ -316,6 +316,12 @@ __device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_
 // (Ctx::kSkip: the same holds for the size-like sub-walks the emit kernel runs inside such a tile -- SkipCtx below.)
 #define RH_TRUST ((EMIT && !CAREFUL) || Ctx::kSkip)
 #define RH_REJECT(L, ...) do { if constexpr (!RH_TRUST) reject<CAREFUL>(L, __VA_ARGS__); } while (0)
+// The fast walk's common anomalies (a head outside the single-read forms, a negative length, a bad boolean) only MARK
+// the lane: the whole wave is walked again carefully anyway, so the lane goes on with whatever it decoded -- its results
+// are never used -- and leaves at the next list iteration (h_list_next), which is what bounds its work.  No live / pres /
+// stack upkeep per head: k_size -2 % (profiles/r03bf_soft_rejects_ab.txt).  Anomalies that guard a memory access or a
+// loop (enum / union index range, the N4 leaves, list block headers) still take the lane out on the spot (RH_REJECT).
+#define RH_REJECT_SOFT(L, cond, ...) do { if constexpr (!RH_TRUST) { if constexpr (CAREFUL) reject<true>(L, cond, __VA_ARGS__); else L.redo = L.redo || (cond); } } while (0)
 
 // --------------------------------------------------------------------------
 // primitive readers (fast_decode.rs:845-922)
@@ -463,8 +469,7 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
       }
     }
   } else {
-    reject<false>(L, slow, 0);
-    isval = isval && !slow;
+    L.redo = L.redo || slow;       // (marked, not taken out: see RH_REJECT_SOFT)
   }
   L.cur += dec ? adv : 0u;
   return isval;
@@ -556,8 +561,8 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     const bool eob = (!CAREFUL && !RH_TRUST) ? false : (want && avail < need);      // (fast size walk: see read_head)
     bits = op.a == FK_F32 ? (uint64_t)(uint32_t)x : op.a == FK_F64 ? x : (x & 0xFFu);
     const bool badb = want && !eob && op.a == FK_BOOL && bits > 1;   // read_bool, 893-900
-    RH_REJECT(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
-    RH_REJECT(L, badb, E_BOOL, (int64_t)bits);
+    RH_REJECT_SOFT(L, eob, op.a == FK_F32 ? E_EOB_F32 : op.a == FK_F64 ? E_EOB_F64 : E_EOB);
+    RH_REJECT_SOFT(L, badb, E_BOOL, (int64_t)bits);
     valid = want && L.live;
     L.cur += valid ? need : 0u;
   }
@@ -600,8 +605,8 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
     const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
     // (the fast size walk checks a record's bounds once, at its end: see read_head)
     const bool eob = (!CAREFUL && !RH_TRUST) ? false : (want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur));
-    RH_REJECT(L, neg, E_NEGLEN);
-    RH_REJECT(L, eob, E_EOB_STR);
+    RH_REJECT_SOFT(L, neg, E_NEGLEN);
+    RH_REJECT_SOFT(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
     spos = L.cur;
     L.cur += len;
@@ -854,6 +859,7 @@ __device__ __forceinline__ void list_next_slow(const Ctx& c, const Src& src, Lan
 template <bool CAREFUL, bool TRUST = false, class Src, class Ctx>
 __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   uint32_t& rm = c.remaining(op.c);
+  if constexpr (!CAREFUL && !TRUST) L.live = L.live && !L.redo;      // a lane that has met an anomaly (RH_REJECT_SOFT) stops iterating here
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
   if (TRUST) {               // every block header of this tile took the one-read form below in the size pass, unclamped
     uint32_t raw, n;
