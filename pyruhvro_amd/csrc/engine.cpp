@@ -1046,6 +1046,16 @@ struct rh_decode_call {
     const uint64_t lds_cap = 160 * 1024 - 512;
     if (lds_fixed + 4096 > lds_cap) throw rh::SchemaError("schema needs more LDS than a CDNA4 workgroup has");
     win = std::min<uint64_t>(win, std::min<uint64_t>((lds_cap - lds_fixed) & ~15ull, 96 * 1024));
+    // Occupancy steps: a CU's 160 KB hold N workgroups of at most 160 KB / N each.  A window that puts the workgroup just
+    // above a step costs a whole workgroup per CU (a quarter of the resident waves at N = 4) for a few hundred bytes of
+    // slack, so it gives that slack up as long as a smaller margin (6 % + 1 KB over the mean tile) is left.
+    if (win_pct == 115 && win_pad == 2048) {       // (not when a test / sweep sets the window by hand)
+      const uint64_t min_win = align_up(avg * tile * 106 / 100 + 1024 * tile / rh::kBlock, 16);
+      for (uint64_t nwg = 4; nwg >= 2; nwg--) {        // (4: what the emit kernel's registers allow at most)
+        const uint64_t step = (160 * 1024 / nwg) & ~511ull;
+        if (lds_fixed + win > step && step > lds_fixed && step - lds_fixed >= min_win) { win = (step - lds_fixed) & ~15ull; break; }
+      }
+    }
     P.win_bytes = (uint32_t)win;
     lds_bytes = lds_fixed + (uint32_t)win;
     // optional in-kernel phase timing of the specialised kernels (RUHVRO_HIP_PROFILE=1)

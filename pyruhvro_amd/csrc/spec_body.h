@@ -74,7 +74,8 @@ struct SCtx {
   // v_readlane reloads of spilled SGPRs.
   const __attribute__((address_space(4))) uint64_t* bufp;
   uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
-  uint32_t* nullcnt;                                  // LDS [NNODES]
+  uint32_t* nullcnt;                                  // LDS [NNODES]: null rows of child domains (one atomic per null row)
+  uint32_t* nullw_w;                                  // LDS [NNODES][NW] + this wave: null rows of domain-0 fields, per wavefront
   const uint32_t* sym_off;
   const uint8_t* sym_data;
   uint32_t lrow, lane;
@@ -88,8 +89,15 @@ struct SCtx {
   static __device__ __forceinline__ bool enum_sym(int b, uint32_t v, uint32_t& len, uint64_t& bits) { return S::enum_sym(b, v, len, bits); }
   // no per-node accumulators (NNODES wave-uniform registers that spill): one LDS add per field and wave
   // (k_emit 0.950 -> 0.937 ms, profiles/r02a_variants_ab.txt)
+  // A domain-0 field is visited exactly once per wavefront and tile, so its null count of the wave is a plain store into
+  // the wave's own word (summed per tile at the flush), not an atomic add: the compiler expands a wave-uniform LDS atomic
+  // into ~19 instructions (its atomic optimiser: mbcnt / bcnt / mul around a single-lane ds_add) per nullable field.
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
+#ifdef RH_V_NONULLW
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
+#else
+    if (lane == 0) nullw_w[node * (S::TILE / 64)] = n;
+#endif
   }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
   // Bits of child-domain bitmaps (validity / boolean values of list items, map values ...).  A tile's rows of a child
@@ -152,10 +160,10 @@ __device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[
   }
 }
 
-// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
+// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | nullw[NNODES][NW] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
 // a dense list) | bmw0[NB0][NW] u64   (host mirror: spec_lds_fixed_words_host)
 __host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
-  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
+  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
          (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
 }
 
@@ -171,6 +179,7 @@ template <class S>
 struct SpecSmem {
   uint32_t* wtot;
   uint32_t* nullcnt;
+  uint32_t* nullw;
   uint32_t* misc;
   uint32_t* bm;
   uint32_t* dtab;
@@ -180,6 +189,7 @@ struct SpecSmem {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
     wtot = p; p += ((S::K > 0 ? S::K : 1) * (S::TILE / 64) + 3) & ~3;
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
+    nullw = p; p += ((S::NNODES * (S::TILE / 64) + 3) & ~3);
     misc = p; p += 4;
     bm = p; p += S::NBM * kBmWords;                   // a multiple of 16 bytes
     dtab = p; p += S::NDENSE > 0 ? (S::TILE / 64) * kDenseCap : 0;
@@ -295,7 +305,7 @@ template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
   static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
-  c.nullcnt = s.nullcnt; c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
+  c.nullcnt = s.nullcnt; c.nullw_w = s.nullw + (tid >> 6); c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
   c.dtab = s.dtab + (tid >> 6) * kDenseCap; c.wtot_w = s.wtot + (tid >> 6);
   c.bmw0 = s.bmw0;
@@ -432,6 +442,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(0);
   if (fits) stage_window<T>(P, s.win, wb16, we, tid);
   for (int i = tid; i < S::NNODES; i += T) s.nullcnt[i] = 0;
+  for (int i = tid; i < S::NNODES * NW; i += T) s.nullw[i] = 0;
   for (int i = tid; i < S::NBM * kBmWords; i += T) s.bm[i] = 0;
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
@@ -477,7 +488,8 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   report_errors(P, s.misc, L, g, tid, tile);   // barrier inside: nullcnt + staging complete
   RH_MARK(8);
   for (int i = tid; i < S::NNODES; i += T) {
-    const uint32_t v = s.nullcnt[i];
+    uint32_t v = s.nullcnt[i];
+    for (int w = 0; w < NW; w++) v += s.nullw[i * NW + w];
     if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * kNullSlots + (tile & (kNullSlots - 1))], v);
   }
   if constexpr (S::NB0 > 0) {   // the tile's domain-0 bitmap words (SCtx::put_word0): one lane per word
