@@ -112,7 +112,46 @@ def stamped_traffic(schema_json: str, encode: bool = False):
         return {}
 
 
-def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int):
+def count_buffers(batch) -> int:
+    """Arrow buffers (present ones) of every node of a RecordBatch."""
+    import pyarrow as pa
+
+    def walk(a):
+        t = a.type
+        c = sum(1 for b in a.buffers()[: 3 if (pa.types.is_string(t) or pa.types.is_binary(t)) else 2 if not pa.types.is_struct(t) else 1] if b is not None)
+        if pa.types.is_struct(t) or pa.types.is_union(t):
+            c += sum(walk(a.field(i)) for i in range(t.num_fields))
+        elif pa.types.is_map(t):
+            c += walk(a.keys) + walk(a.items)
+        elif pa.types.is_list(t):
+            c += walk(a.values)
+        return c
+    return sum(walk(batch.column(i)) for i in range(batch.num_columns))
+
+
+def parity_check(cs, data, offsets, num_chunks: int, got, config: str):
+    """The batches ONE call of the timed configuration produced (settled and copied to the host after the timed regions)
+    against the oracle's decode of the same records -- every buffer of every node of every chunk, bit-exact
+    (tests/arrow_compare.py, the bar of the GPU parity suite; the reference's own check is assert_round_trip,
+    ruhvro/src/fast_decode.rs:945-953).  The oracle is the checker here, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from arrow_compare import assert_batches_identical
+    from oracle import c_walker
+    t = time.perf_counter()
+    exp = c_walker.decode_packed(cs, data, offsets, num_chunks, threaded=True)
+    out = {"config": config, "records": int(len(offsets) - 1), "chunks": len(exp), "buffers": 0, "result": "identical"}
+    try:
+        assert len(got) == len(exp), f"{len(got)} chunks, the oracle has {len(exp)}"
+        for g, e in zip(got, exp):
+            assert_batches_identical(g, e)
+            out["buffers"] += count_buffers(g)
+    except AssertionError as e:
+        out["result"] = "DIFFERENT: " + str(e)[:300]
+    out["check_s"] = round(time.perf_counter() - t, 2)
+    return out
+
+
+def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int, parity_of=None):
     """Oracle C walker ("port" of ruhvro/src/fast_decode.rs) with the reference's threading shape (serial pack + one task
     per chunk, ruhvro/src/deserialize.rs:76-121), on the SAME inputs as the GPU leg, best of 5 after a warm-up: once
     with the workload's own num_chunks (= threads), once with as many chunks as this host has cores (capped at 64) so
@@ -135,16 +174,19 @@ def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int)
     wide = max(num_chunks, min(64, ncpu))
     out = {
         "value": timed(num_chunks), "unit": "records/s", "cores": num_chunks, "kind": "port",
-        "sample": f"all {n_sample} records of the workload, {num_chunks} chunks = {num_chunks} threads "
-                  f"(reference shape: serial pack + one task per chunk), best of 5; host has {ncpu} cpus",
+        "sample": f"all {n_sample} records, {num_chunks} chunks = {num_chunks} threads (serial pack + 1 task per chunk), best of 5; {ncpu} cpus",
     }
     if wide != num_chunks:
         out["wide"] = {"value": timed(wide), "unit": "records/s", "cores": wide,
                        "sample": f"same records, {wide} chunks = {wide} threads (what the reference would use with num_chunks={wide}), best of 5"}
-    return out
+    parity = None
+    if parity_of is not None:       # (got batches, description) of one call of the timed GPU configuration on these same records
+        got, config = parity_of
+        parity = parity_check(cs, data, offsets, num_chunks, got, config)
+    return out, parity
 
 
-def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sample: int = 2_000_000):
+def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int):
     """Host in -> host out through the C ABI's host entry points (PCIe-inclusive), best of 3 each, with the engine's
     stage timings (rh_stats).  The payload is generated once; slices point into it."""
     import numpy as np
@@ -179,19 +221,33 @@ def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int, py_sampl
                                                                         devices=[0] * num_chunks))
     out["packed_8_logical_shards"]["what"] = (f"rh_decode_packed with rh_opts.devices = [0] * {num_chunks}: the in-process multi-GPU driver "
                                               "(one host thread + stream per shard) on this one GPU")
-    m = min(py_sample, n)
-    recs = fastgen.split(data[: int(offsets[m])], offsets[: m + 1])
-    P.deserialize_array_threaded(recs, schema_json, num_chunks)
-    best = float("inf")
-    for _ in range(2):
-        t = time.perf_counter()
-        res = P.deserialize_array_threaded(recs, schema_json, num_chunks)
-        best = min(best, time.perf_counter() - t)
-        del res
-    out["python_list_bytes"] = {"value": m / best, "wall_ms": best * 1e3, "records": m,
-                                "what": f"pyruhvro_amd.deserialize_array_threaded(list[bytes], schema, {num_chunks}) on a {m}-record sample"}
+    # The Python surface itself at the metric's own sizes (BASELINE.json quotes 10k / 1M / 10M through
+    # deserialize_array_threaded, src/lib.rs:73-89): list[bytes] in, list[RecordBatch] out, best of 3, with the boundary's
+    # phase split (pyruhvro_amd.last_decode_profile(): set-up, extraction, rest of the engine call, GIL-held time).
+    recs = fastgen.split(data, offsets)
+    out["python_list_bytes"] = {}
+    for m in sorted({min(x, n) for x in (1_000_000, 10_000_000)}):
+        sub = recs if m == n else recs[:m]
+        P.deserialize_array_threaded(sub, schema_json, num_chunks)
+        best, prof = float("inf"), None
+        for _ in range(3):
+            t = time.perf_counter()
+            res = P.deserialize_array_threaded(sub, schema_json, num_chunks)
+            w = time.perf_counter() - t
+            if w < best:
+                best, prof = w, P.last_decode_profile()
+            del res
+        out["python_list_bytes"][str(m)] = {
+            "value": m / best, "wall_ms": best * 1e3, "records": m,
+            "gil_held_ms": round(prof["gil_held_ms"], 3),
+            "phase_ms": {k: round(prof[k], 3) for k in ("alloc_setup_ms", "extract_ms", "engine_tail_release_ms", "total_ms")},
+            "streaming_handover": bool(prof["streaming"]),
+            "vs_record_slices": (m / best) / out["record_slices"]["value"] if out["record_slices"]["value"] else None,
+            "what": f"pyruhvro_amd.deserialize_array_threaded(list[bytes] of {m} records, schema, {num_chunks}), host in -> host out, best of 3"}
+        del sub
     # BASELINE config 1: the reference's own CPU-runnable case, 10,000 records through the Python surface
     small = recs[:10_000]
+    del recs
     for _ in range(20):
         P.deserialize_array_threaded(small, schema_json, num_chunks)
     t = time.perf_counter()
@@ -234,7 +290,7 @@ def run(args, make_step=None, backend="nccl"):
     step, info = make_step(gen_cfg, shard, dev, local_rank)
 
     def sync():
-        if world > 1:
+        if world > 1 or dist.is_initialized():      # (BENCH_FORCE_DIST: the one-rank group runs the same collectives)
             dist.barrier(device_ids=[local_rank]) if use_cuda else dist.barrier()
         if use_cuda:
             torch.cuda.synchronize()
@@ -296,6 +352,10 @@ def run(args, make_step=None, backend="nccl"):
 
     run.info = info
     run.step = step
+    run.dist = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                 "collectives": ["barrier(device_ids)" if use_cuda else "barrier", "all_reduce(MAX) of the per-rank wall time",
+                                 f"all_gather of a {len(rdist.STAT_KEYS)}-double stats vector"]}
+                if dist.is_available() and dist.is_initialized() else None)
     local = {"records": shard["rows"], "input_bytes": info["input_bytes"], "output_bytes": info["output_bytes"],
              "step_ms": wall * 1e3 / args.steps}
     for k in acc:
@@ -434,6 +494,18 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
         torch.cuda.synchronize()
         return (time.perf_counter() - t) * 1e3 / reps
     step.sync_call_ms = sync_call_ms
+
+    def parity_batches():
+        """One more call of the TIMED configuration (rh_decode_device + RH_ASYNC on the timed stream, the shard's chunk
+        geometry), settled and copied to the host: what `parity_check` compares with the oracle."""
+        c = pipe.calls[0]
+        h = c.run(False)
+        try:
+            c.wait(h, False)
+            return c.to_host(h)
+        finally:
+            c.free(h)
+    step.parity_batches = parity_batches
 
     step.rank_step = rank_step
     step.keepalive = (d_data, d_off, extra)
@@ -747,6 +819,8 @@ def main(argv=None):
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": roofline,
     }
+    if getattr(run, "dist", None):
+        out["dist"] = run.dist
     if getattr(run, "overlapped", None):
         ov = run.overlapped
         total = sum(r["records"] for r in per_rank) * args.steps
@@ -762,7 +836,16 @@ def main(argv=None):
         out["config5_projection"] = config5_projection(run.step, wall * 1e3 / args.steps, num_chunks,
                                                        overlapped_1gpu=getattr(run, "overlapped", None))
     if not args.no_cpu_baseline and world == 1:   # the CPU port is timed at N=1 only (rank 0's host cores)
-        out["cpu_baseline"] = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], min(args.cpu_sample, n) if args.cpu_sample else n, num_chunks)
+        n_cpu = min(args.cpu_sample, n) if args.cpu_sample else n
+        got = None
+        if n_cpu == n and hasattr(run.step, "parity_batches"):       # the oracle decodes the whole workload: check the timed configuration against it
+            got = (run.step.parity_batches(),
+                   f"rh_decode_device + RH_ASYNC on the timed stream, {n} records, num_chunks={num_chunks}, kernel form of the timed steps, "
+                   "every chunk copied to the host after the timed regions")
+        out["cpu_baseline"], parity = cpu_baseline(gen_cfg, SCHEMAS[gen_cfg], n_cpu, num_chunks, got)
+        del got
+        if parity:
+            out["parity_check"] = parity
     if not args.no_end_to_end and world == 1:
         out["end_to_end"] = end_to_end(gen_cfg, SCHEMAS[gen_cfg], n, num_chunks)
     if not args.no_other_configs and not args.no_end_to_end and world == 1 and shard_whole:     # (profiler passes give --no-end-to-end)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 4
+#define RH_ABI_VERSION 5
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -73,7 +73,10 @@ typedef struct {
    * repeat (several logical shards on one GPU).  NULL / 0 = the single device named by `device`. */
   const int32_t* devices;
   uint32_t n_devices;
-  uint32_t reserved0;
+  /* sizeof(rh_opts) as the caller compiled it, or 0.  0 = the ABI-3 layout, which ends with `device_stats`: the engine
+   * then never reads the fields behind it, so a caller built against the shorter struct stays safe (the field was
+   * `reserved0`, must-be-zero, in ABI 3).  Set it to sizeof(rh_opts) to use `ready` / `gathered`. */
+  uint32_t struct_size;
   /* Explicit chunk geometry for a caller that decodes a RANGE of a larger call's chunks (one process per GPU, each
    * holding whole reference chunks): when non-zero, the n records are `num_chunks` chunks of `chunk_rows` rows, the
    * last one taking the rest (deserialize.rs:57-68 applied to the whole list, not to this range).  0 = the
@@ -87,7 +90,8 @@ typedef struct {
    * the H2D copy, the kernels and the D2H copy of the first groups overlap the producer's work on the later ones.
    * *gathered (optional) is the engine's answer: the number of leading records whose BYTES it has copied and will
    * not read again -- the caller may let go of them (the CPython boundary drops its references while the tail of the
-   * call is still on the PCIe link).  NULL / NULL = every entry is valid at entry, the classic call. */
+   * call is still on the PCIe link).  NULL / NULL = every entry is valid at entry, the classic call.  Read only when
+   * struct_size covers them. */
   const uint64_t* ready;
   uint64_t* gathered;
 } rh_opts;
@@ -104,7 +108,12 @@ typedef struct {
  * The result's device buffers are valid in stream order on rh_opts.stream, like any asynchronous HIP work; what the
  * HOST learns from a call -- the first malformed record (the in-order join of deserialize.rs:115-119), row counts,
  * null counts, an arena that has to be re-laid-out -- is settled by rh_device_result_wait(), which every accessor of
- * an unsettled result also runs first.  The input buffers AND the compiled schema must stay alive until then.  A schema's first call on a
+ * an unsettled result also runs first.  Until then the input buffers (d_data, d_offsets) must stay alive AND UNMODIFIED,
+ * and the compiled schema alive: the emit pass re-reads the records the size pass cleared and, in tiles without
+ * anomalies, walks them with no bounds or anomaly predicate of its own (walk.h RH_TRUST) -- bytes that change between
+ * the two passes (a caller recycling d_data on another stream) turn into unchecked stores.  Work that reuses the
+ * buffers must be ordered behind the call on rh_opts.stream, or wait for rh_device_result_wait.  (RUHVRO_HIP_NO_TRUST=1
+ * makes the emit pass walk every tile with its own checks -- a debugging aid, ~1.3x the kernel time.)  A schema's first call on a
  * device (no size history to reserve the arena from) completes synchronously whatever the flag says.  This is how a
  * pipeline of small batches keeps the GPU busy: a 1M-record call is 0.15 ms of kernels, and a synchronous call adds
  * ~25 us of host turn-around during which the GPU idles. */
@@ -160,7 +169,8 @@ int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offse
  * call).  A no-op returning RH_OK on a result that is already settled.  Not thread-safe per result. */
 int rh_device_result_wait(rh_device_result* r, rh_stats* stats, char** err);
 uint32_t rh_device_result_chunks(const rh_device_result* r);
-/* Exact (unpadded) Arrow buffer bytes the call produced, all chunks. */
+/* Exact (unpadded) Arrow buffer bytes the call produced, all chunks.  Settles an RH_ASYNC result first; 0 when that
+ * call failed (rh_device_result_wait reports the message -- this accessor has no error channel). */
 uint64_t rh_device_result_output_bytes(const rh_device_result* r);
 /* Arrow C Device Data Interface view of chunk i (device_type ARROW_DEVICE_ROCM);
  * valid until rh_device_result_free; release the view through array.release. */
@@ -216,7 +226,8 @@ enum {
   RH_CTR_CAPACITY_RETRIES = 2, /* LF_CAPACITY: the arena reserved from the size history was too small, tail re-run  */
   RH_CTR_WIDE_FALLBACKS = 3,   /* NeedWideIndex: a call re-run on the generic kernels (64-bit in-buffer offsets)    */
   RH_CTR_OFFSET32_ERRORS = 4,  /* calls refused because a chunk's column exceeds 32-bit Arrow offsets               */
-  RH_CTR_COUNT = 5
+  RH_CTR_SPLIT_CALLS = 5,      /* device-resident calls that dealt their chunk groups to internal streams (in-call overlap) */
+  RH_CTR_COUNT = 6
 };
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 
@@ -224,6 +235,10 @@ void rh_free_string(char* s);
 int rh_abi_version(void);
 /* Number of visible HIP devices (0 when no GPU / driver); never throws. */
 int rh_device_count(void);
+/* The calling thread's current HIP device (what rh_opts.device = -1 resolves to on this thread), or -1 when there is
+ * none.  The current device is per host thread: a binding that moves a call to a thread of its own resolves -1 with
+ * this BEFORE it starts the thread (the CPython boundary does, pymodule.cpp).  Never throws. */
+int rh_current_device(void);
 
 #ifdef __cplusplus
 }

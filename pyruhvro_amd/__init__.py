@@ -177,6 +177,13 @@ def deserialize_array_threaded_with_stats(list, schema, num_chunks, device: int 
     return _decode(list, schema, num_chunks, want_stats=True, device=device)
 
 
+def last_decode_profile():
+    """Extension: where this thread's most recent ``deserialize_array*`` call spent its time at the CPython boundary --
+    set-up, list extraction, the rest of the engine call, the total, and how long the call held the GIL (milliseconds)."""
+    _require_native()
+    return _native.last_decode_profile()
+
+
 def deserialize_binary_array(array, schema, num_chunks):
     """Extension: the same decode for records that already sit in an Arrow
     ``BinaryArray`` / ``LargeBinaryArray`` (one record per element) -- the form the reference packs its

@@ -31,9 +31,9 @@ class RhStats(C.Structure):
 
 
 class RhOpts(C.Structure):
-    """rh_opts (ABI version 4).  Build with make_opts()."""
+    """rh_opts (ABI version 5: `struct_size` took the place of ABI 3's must-be-zero `reserved0`).  Build with make_opts()."""
     _fields_ = [("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
-                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("reserved0", C.c_uint32),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("struct_size", C.c_uint32),
                 ("chunk_rows", C.c_uint64), ("device_stats", C.POINTER(RhStats)),
                 ("ready", C.POINTER(C.c_uint64)), ("gathered", C.POINTER(C.c_uint64))]   # streaming hand-over (rh_decode): NULL = off
 
@@ -42,6 +42,7 @@ def make_opts(device: int = -1, kernel: int = 0, stream=None, devices=None, chun
     """-> (RhOpts, keepalive).  `devices`: sequence of HIP ordinals to shard the chunks over (repeats allowed);
     per-shard stats land in keepalive["device_stats"]."""
     o = RhOpts()
+    o.struct_size = C.sizeof(RhOpts)
     o.device, o.flags, o.stream = device, kernel, stream or None
     o.chunk_rows = chunk_rows
     keep = {}
@@ -119,6 +120,7 @@ def lib():
         L.rh_schema_kernel_key.argtypes = [C.c_void_p, C.c_int]
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
+        L.rh_current_device.restype = C.c_int
         L.rh_device_count.restype = C.c_int
         L.rh_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(RhOpts), C.POINTER(C.c_void_p),
                                        C.POINTER(RhStats), C.POINTER(C.c_char_p)]
@@ -135,7 +137,7 @@ def lib():
     return _lib
 
 
-ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors")
+ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls")
 
 
 def engine_counters() -> dict:
@@ -485,3 +487,13 @@ class PreparedDeviceDecode:
     def free(self, handle: int) -> None:
         self._free(handle)
 
+
+    def to_host(self, handle: int) -> List[pa.RecordBatch]:
+        """rh_device_result_to_host of a run()'s result (settles an asynchronous one first); the handle stays the caller's
+        to free."""
+        k = int(self._L.rh_device_result_chunks(handle))
+        arr = (ArrowArray * k)()
+        rc = self._L.rh_device_result_to_host(handle, arr, self._e)
+        if rc != RH_OK:
+            _raise(rc, self._err)
+        return _import_chunks(arr, k, self._schema.arrow_schema)

@@ -47,7 +47,7 @@ int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
 int rh_launch_layout(const rh::LParams* L, void* stream);
-int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token, void* stream);
+int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
@@ -504,6 +504,12 @@ struct rh_device_result {
   std::exception_ptr fail;             // what settle() found: every later accessor reports it again
   rh_stats st;                         // stage timings of an asynchronous call that asked for them
   bool has_stats = false;
+  // A call that dealt its chunk groups to internal streams (decode_device_split): one complete result per group, in
+  // chunk order; part g holds chunks [part_chunk0[g], part_chunk0[g + 1]) of this call.  The fields above other than
+  // cs / device / n / k / sz / rows_last / fail are then unused.
+  std::vector<std::unique_ptr<rh_device_result>> parts;
+  std::vector<uint32_t> part_chunk0;
+  std::vector<hipEvent_t> join_events;  // recorded on the internal streams, waited for by the caller's stream (recycled on free)
 
   rh_device_result();
   ~rh_device_result();
@@ -726,6 +732,9 @@ void export_field(const rh::ArrowField& f, ArrowSchema* out) {
 // the launch sequence
 // ---------------------------------------------------------------------------
 // integer knob from the environment, read at every use (tests change them inside one process); out of range = default
+constexpr long kInternalStreamsDefault = 1;      // RUHVRO_HIP_INTERNAL_STREAMS (decode_device_split)
+constexpr long kSplitMinDefault = 1000000;       // RUHVRO_HIP_SPLIT_MIN: records below which a call is never split
+
 long env_long(const char* name, long dflt, long lo, long hi) {
   const char* e = std::getenv(name);
   if (!e || !*e) return dflt;
@@ -806,10 +815,40 @@ struct ChunkGeo {
 rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
                                       uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats, const ChunkGeo* geo);
 
+rh_device_result* decode_device_split(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len, uint64_t n,
+                                      const rh_opts& opts, uint32_t k, uint64_t sz, uint64_t rows_last, unsigned G);
+
 rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len,
                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats,
                                      const ChunkGeo* geo = nullptr) {
   try {
+    // in-call overlap (decode_device_split): a large call deals its chunk groups to internal streams
+    const long G = env_long("RUHVRO_HIP_INTERNAL_STREAMS", kInternalStreamsDefault, 1, 8);
+    if (G > 1 && !geo && !stats && n >= (uint64_t)env_long("RUHVRO_HIP_SPLIT_MIN", kSplitMinDefault, 1, 1l << 40) &&
+        (!opts || (opts->flags & 3) != RH_KERNEL_GENERIC) && s->arena_ratio.load() > 0 && env_long("RUHVRO_HIP_TWO_SYNC", 0, 0, 1) == 0 &&
+        env_long("RUHVRO_HIP_ARENA_PERMILLE", -1, 0, 1000000) < 0) {
+      const rh_opts o = opts ? *opts : default_opts();
+      uint64_t k64 = rh_clamp_chunks(n, num_chunks), sz = n / std::max<uint64_t>(k64, 1);
+      bool ok = true;
+      if (o.chunk_rows) {        // explicit geometry: validated by the unsplit path when it does not hold
+        ok = num_chunks >= 1 && num_chunks <= 0xFFFFFFFFull && (num_chunks - 1) <= n / o.chunk_rows &&
+             !(n > 0 && n == (num_chunks - 1) * o.chunk_rows && num_chunks > 1);
+        k64 = num_chunks; sz = o.chunk_rows;
+      }
+      const unsigned g = (unsigned)std::min<uint64_t>((uint64_t)G, k64);
+      if (ok && g > 1 && !((uintptr_t)d_data & 15)) {
+        const uint64_t rows_last = n - (k64 - 1) * sz;
+        try {
+          if (rh_device_result* r = decode_device_split(s, d_data, d_offsets, data_len, n, o, (uint32_t)k64, sz, rows_last, g)) return r;
+        } catch (const NeedWideIndex&) {
+          // (a child row domain beyond 32-bit indexing: the whole call goes to the generic kernels below, unsplit)
+          count(RH_CTR_WIDE_FALLBACKS);
+          rh_opts o2 = o;
+          o2.flags = (o.flags & ~3) | RH_KERNEL_GENERIC;
+          return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o2, stats, geo);
+        }
+      }
+    }
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats, geo);
   } catch (const NeedWideIndex&) {
     count(RH_CTR_WIDE_FALLBACKS);
@@ -852,6 +891,7 @@ struct rh_decode_call {
   uint64_t narrow_rows = 0, tile = 0, bpc64 = 0, payload = 0;
   uint32_t nblocks = 0;
   uint64_t o_null = 0, o_tot = 32, ctrl_bytes = 0;
+  uint32_t null_slots = rh::kNullSlots;      // program.h null_slots_for(k)
   Lease ws, hctrl, dtab, prof_buf;
   std::unique_ptr<CtrlLease> ctrl;
   rh::KParams P;
@@ -867,6 +907,9 @@ struct rh_decode_call {
   bool settled = false;         // finish() ran (or the call completed inside enqueue())
   bool async = false;           // RH_ASYNC: the call is settled later; without rh_k_publish its end is marked with a DoneEvent
   DoneEvent done;
+  // in-call overlap (decode_device_split, staggered form): this group's size pass starts behind `start_after` (the previous
+  // group's size pass) and marks its own end with `sized`, so that size pass g+1 runs beside emit pass g
+  hipEvent_t start_after = nullptr, sized = nullptr;
   bool published = false;       // rh_k_publish ran: hctrl holds the compact layout (summed null counts) behind a token
   uint32_t token = 0;
   uint64_t o_flag_h = 0;
@@ -1001,11 +1044,12 @@ struct rh_decode_call {
     if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
     nblocks = (uint32_t)nblocks64;
 
-    // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*kNullSlots]
+    // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*null_slots]
     //      workspace: errinfo | blocksum | blockbase | tileflag | lanecnt
     o_tot = 32;      // control words first (program.h): first_bad, layout flag, arena bytes used
     o_null = align_up(o_tot + 8ull * K * k, 16);
-    ctrl_bytes = align_up(o_null + 4ull * nnodes * k * rh::kNullSlots, kAlign);
+    null_slots = rh::null_slots_for(k);
+    ctrl_bytes = align_up(o_null + 4ull * nnodes * k * null_slots, kAlign);
     const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
     const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
@@ -1026,6 +1070,7 @@ struct rh_decode_call {
     P.nbuf = nbuf; P.cnt_databuf = dp->cnt_databuf;
     P.first_bad = (unsigned long long*)ctrl->ptr();
     P.nullcount = (uint32_t*)(ctrl->ptr() + o_null);
+    P.null_slots = null_slots;
     P.totals = (uint64_t*)(ctrl->ptr() + o_tot);
     P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
     P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
@@ -1092,16 +1137,24 @@ struct rh_decode_call {
     // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
     // e3..e4 = k_emit
     timed_size = n > 0 && K > 0;
+    if (start_after) HIPCHK(hipStreamWaitEvent(stream, start_after, 0));
     if (timed_size) {
       if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
              : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
         throw HipError("k_size launch failed");
+      if (sized) HIPCHK(hipEventRecord(sized, stream));
       // (the single-submission path scans and lays the arena out in ONE launch, below)
       if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
     } else {
       // no size pass (no variable-length output): nobody classified the tiles, so the emit kernel walks all of them carefully
       P.all_careful = 1;
+      if (sized) HIPCHK(hipEventRecord(sized, stream));
     }
+    // RUHVRO_HIP_NO_TRUST=1 (debugging aid): the emit pass walks EVERY tile with its own bounds and anomaly checks instead of
+    // trusting the size pass's verdict on the same bytes (walk.h RH_TRUST) -- what a caller that suspects its input buffers
+    // change between the two passes of an RH_ASYNC call turns on; the GPU suite passes with it (tests/test_async_device.py)
+    static const bool no_trust = env_long("RUHVRO_HIP_NO_TRUST", 0, 0, 1) != 0;
+    if (no_trust) P.all_careful = 1;
     hp.mark("size+scan_launch");
     basis = (double)payload + 64.0 * (double)n;
     if (fused) {
@@ -1128,7 +1181,7 @@ struct rh_decode_call {
         if (token == 0) token = next_token.fetch_add(1);
         o_flag_h = align_up(o_null + 4ull * nnodes * k, 8);                 // host layout: head | compact null counts | token
         *(volatile uint32_t*)(hctrl.ptr() + o_flag_h) = 0;
-        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, stream))
+        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, stream))
           throw HipError("k_publish launch failed");
         ctrl->b.clean = true;
         published = true;
@@ -1204,10 +1257,10 @@ struct rh_decode_call {
     if (published) {           // rh_k_publish summed the slots: one word per (node, chunk)
       std::memcpy(r.nullcount.data(), hctrl.ptr() + o_null, 4ull * nnodes * k);
     } else {
-      const uint32_t* slots = (const uint32_t*)(hctrl.ptr() + o_null);      // [nnodes][k][kNullSlots] (program.h)
+      const uint32_t* slots = (const uint32_t*)(hctrl.ptr() + o_null);      // [nnodes][k][null_slots] (program.h)
       for (size_t e = 0; e < (size_t)nnodes * k; e++) {
         uint32_t sum = 0;
-        for (int sl = 0; sl < rh::kNullSlots; sl++) sum += slots[e * rh::kNullSlots + sl];
+        for (uint32_t sl = 0; sl < null_slots; sl++) sum += slots[e * null_slots + sl];
         r.nullcount[e] = sum;
       }
     }
@@ -1254,6 +1307,15 @@ rh_device_result::~rh_device_result() {
     pending->drain();
     pending.reset();
   }
+  parts.clear();                 // (each group drains its own stream)
+  if (!join_events.empty()) {
+    std::lock_guard<std::mutex> g(DoneEvent::mu());
+    auto& v = DoneEvent::idle()[device];
+    for (hipEvent_t e : join_events) {
+      if (v.size() < 64) v.push_back(e);
+      else (void)hipEventDestroy(e);
+    }
+  }
 }
 
 namespace {
@@ -1285,11 +1347,132 @@ rh_device_result* decode_device_impl1(rh_schema* s, const uint8_t* d_data, const
 }
 
 
+// ---------------------------------------------------------------------------
+// In-call overlap: a large device-resident call deals its chunk GROUPS to internal streams.
+//
+// The reference runs one task per chunk (ruhvro/src/deserialize.rs:92-120); chunks are independent here too, and the two
+// passes load different parts of a CU (the size pass is bound by VALU issue, the emit pass co-limited by the vector-memory
+// path), so the size pass of one group running beside the emit pass of another fills issue slots that either kernel
+// alone leaves empty (bench.py `overlapped` measured it between independent calls; this is the same inside ONE call).
+// Group g = chunks [k*g/G, k*(g+1)/G) is a complete sub-call (size -> scan+layout -> emit -> publish, its own arena and
+// control block) on its own stream; the caller's stream forks into the internal streams at the start of the call and
+// joins them at its end, so the result is valid in stream order on rh_opts.stream exactly like an unsplit call's.
+// Not taken when the caller asks for stage timings (kernels that share the chip have no per-kernel duration), on a
+// schema's first call (no size history), for the generic kernels, or below RUHVRO_HIP_SPLIT_MIN records.
+// RUHVRO_HIP_INTERNAL_STREAMS=G (1 = off) -- profiler passes run with 1.
+// ---------------------------------------------------------------------------
+void settle(rh_device_result* r);
+
+hipEvent_t pooled_event(int device) {
+  hipEvent_t e = nullptr;
+  {
+    std::lock_guard<std::mutex> g(DoneEvent::mu());
+    auto& v = DoneEvent::idle()[device];
+    if (!v.empty()) { e = v.back(); v.pop_back(); }
+  }
+  if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+
+// the internal streams that accompany one caller stream on one device (created on first use, kept for the process)
+std::vector<hipStream_t> companion_streams(int device, hipStream_t caller, unsigned want) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::vector<hipStream_t>> all;
+  std::lock_guard<std::mutex> g(mu);
+  if (all.size() >= 64 && !all.count({device, caller})) return {};          // a caller that burns through streams: no split
+  auto& v = all[{device, caller}];
+  while (v.size() < want) {
+    hipStream_t x = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    v.push_back(x);
+  }
+  return std::vector<hipStream_t>(v.begin(), v.begin() + want);
+}
+
+rh_device_result* decode_device_split(rh_schema* s, const uint8_t* d_data, const uint64_t* d_offsets, uint64_t data_len, uint64_t n,
+                                      const rh_opts& opts, uint32_t k, uint64_t sz, uint64_t rows_last, unsigned NS) {
+  int device = opts.device;
+  if (device >= 0) HIPCHK(hipSetDevice(device));
+  else HIPCHK(hipGetDevice(&device));
+  hipStream_t caller = (hipStream_t)opts.stream;
+  const std::vector<hipStream_t> extra = companion_streams(device, caller, NS - 1);
+  if (extra.size() != NS - 1) return nullptr;
+  // groups: G >= NS runs of whole chunks, dealt to the NS streams round-robin (RUHVRO_HIP_SPLIT_GROUPS, default = NS);
+  // staggered (RUHVRO_HIP_SPLIT_STAGGER, default on): group g + 1's size pass starts when group g's has finished, so it
+  // runs beside group g's EMIT pass (different bounds) instead of beside its size pass (the same bound)
+  const unsigned G = (unsigned)std::min<uint64_t>(k, (uint64_t)std::max<long>(env_long("RUHVRO_HIP_SPLIT_GROUPS", 0, 0, 64), (long)NS));
+  const bool stagger = env_long("RUHVRO_HIP_SPLIT_STAGGER", 1, 0, 1) != 0;
+  hipEvent_t prev_sized = nullptr;
+  auto parent = std::make_unique<rh_device_result>();
+  parent->cs = s->cs.get(); parent->device = device; parent->n = n; parent->k = k; parent->sz = sz; parent->rows_last = rows_last;
+  const bool async = (opts.flags & RH_ASYNC) != 0;
+  count(RH_CTR_SPLIT_CALLS);
+  // fork: the internal streams start behind everything that is on the caller's stream now (the input buffers' producers)
+  hipEvent_t fork = pooled_event(device);
+  parent->join_events.push_back(fork);
+  HIPCHK(hipEventRecord(fork, caller));
+  for (hipStream_t x : extra) HIPCHK(hipStreamWaitEvent(x, fork, 0));
+  for (unsigned g = 0; g < G; g++) {
+    const uint32_t c0 = (uint32_t)((uint64_t)k * g / G), c1 = (uint32_t)((uint64_t)k * (g + 1) / G);
+    const uint64_t r0 = (uint64_t)c0 * sz, r1 = c1 == k ? n : (uint64_t)c1 * sz;
+    ChunkGeo geo;
+    geo.k = c1 - c0; geo.sz = sz; geo.rows_last = c1 == k ? rows_last : sz;
+    geo.payload_bytes = n ? (uint64_t)((double)data_len * (double)(r1 - r0) / (double)n) : 0;   // (the offsets live on the device)
+    rh_opts o = opts;
+    o.stream = g % NS == 0 ? (void*)caller : (void*)extra[g % NS - 1];
+    o.device = device; o.chunk_rows = 0; o.flags &= ~RH_ASYNC;
+    auto res = std::make_unique<rh_device_result>();
+    auto call = std::make_unique<DeviceDecode>(s, d_data, d_offsets + r0, data_len, r1 - r0, (uint64_t)geo.k, &o, false, &geo, *res);
+    call->async = true;
+    if (stagger) {
+      call->start_after = prev_sized;
+      if (g + 1 < G) {
+        prev_sized = pooled_event(device);
+        parent->join_events.push_back(prev_sized);
+        call->sized = prev_sized;
+      }
+    }
+    try {
+      call->enqueue();
+      if (call->fused) {
+        res->pending = std::move(call);
+      } else {
+        call->finish();
+      }
+    } catch (...) {
+      call->drain();
+      throw;                      // (the groups already enqueued drain in the parent's destructor)
+    }
+    parent->part_chunk0.push_back(c0);
+    parent->parts.push_back(std::move(res));
+  }
+  // join: the caller's stream continues behind every group
+  for (hipStream_t x : extra) {
+    hipEvent_t e = pooled_event(device);
+    parent->join_events.push_back(e);
+    HIPCHK(hipEventRecord(e, x));
+    HIPCHK(hipStreamWaitEvent(caller, e, 0));
+  }
+  if (!async) settle(parent.get());
+  return parent.release();
+}
+
 // The host's half of an asynchronous call (RH_ASYNC): wait for the stream, check for a malformed record, retry with an
 // exact arena if the reserved one was too small, fall back to the generic kernels if a child row domain needs 64-bit
 // indexing.  Throws what the synchronous call would have thrown; a failed result stays failed.
 void settle(rh_device_result* r) {
   if (r->fail) std::rethrow_exception(r->fail);
+  if (!r->parts.empty()) {
+    // groups are settled in chunk order: the first failure is the lowest failing group's, i.e. the lowest malformed
+    // record of the call (the in-order join of deserialize.rs:115-119)
+    try {
+      for (auto& p : r->parts) settle(p.get());
+    } catch (...) {
+      r->fail = std::current_exception();
+      throw;
+    }
+    return;
+  }
   if (!r->pending) return;
   std::unique_ptr<DeviceDecode> call = std::move(r->pending);
   try {
@@ -1356,6 +1539,20 @@ Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStrea
 
 int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream = nullptr) {
   settle(r);
+  if (!r->parts.empty()) {
+    uint32_t built = 0;
+    try {
+      for (size_t g = 0; g < r->parts.size(); g++) {
+        to_host_impl(r->parts[g].get(), out_chunks + r->part_chunk0[g], stream);
+        built = r->part_chunk0[g] + r->parts[g]->k;
+      }
+    } catch (...) {
+      for (uint32_t c = 0; c < built; c++)
+        if (out_chunks[c].release) out_chunks[c].release(&out_chunks[c]);
+      throw;
+    }
+    return 0;
+  }
   r->tables();
   Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
   slab->refs.store(1);   // guard while building
@@ -1731,8 +1928,10 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
   hipStream_t user_stream = opts ? (hipStream_t)opts->stream : nullptr;
   if (multi && user_stream) throw std::invalid_argument("a multi-device call runs on the engine's own streams (stream must be NULL)");
   // streaming hand-over (rh_opts.ready): the producer is still filling ptrs[] / lens[]; entries [0, *ready) are valid
-  const uint64_t* const ready_ctr = (opts && src.slices()) ? opts->ready : nullptr;
-  uint64_t* const gathered_ctr = (opts && src.slices()) ? opts->gathered : nullptr;
+  // (rh_opts.struct_size: a caller built against the ABI-3 struct, which ends before these two fields, leaves it 0)
+  const bool has_handover = opts && opts->struct_size >= offsetof(rh_opts, gathered) + sizeof(uint64_t*);
+  const uint64_t* const ready_ctr = (has_handover && src.slices()) ? opts->ready : nullptr;
+  uint64_t* const gathered_ctr = (has_handover && src.slices()) ? opts->gathered : nullptr;
   auto wait_ready = [&](uint64_t upto) {
     if (!ready_ctr) return;
     for (uint32_t spins = 0;; spins++) {
@@ -2014,6 +2213,13 @@ int rh_device_count(void) {
   return n;
 }
 
+int rh_current_device(void) {
+  int n = 0, d = -1;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -1;
+  if (hipGetDevice(&d) != hipSuccess) return -1;
+  return d;
+}
+
 void rh_free_string(char* s) { std::free(s); }
 
 uint32_t rh_clamp_chunks(uint64_t n, uint64_t num_chunks) {   // deserialize.rs:53-55
@@ -2132,6 +2338,11 @@ uint64_t rh_device_result_output_bytes(const rh_device_result* r) {
   if (!r) return 0;
   try {
     settle(const_cast<rh_device_result*>(r));
+    if (!r->parts.empty()) {
+      uint64_t sum = 0;
+      for (auto& p : r->parts) { p->tables(); sum += p->output_bytes; }
+      return sum;
+    }
     const_cast<rh_device_result*>(r)->tables();
   } catch (...) {
     return 0;                  // a failed asynchronous call produced nothing (rh_device_result_wait has the message)
@@ -2153,8 +2364,11 @@ int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDev
   std::memset(out, 0, sizeof *out);
   try {
     settle(r);
-    r->tables();
-    export_chunk(*r, chunk, r->arena.ptr(), nullptr, &out->array);
+    rh_device_result* owner = r;
+    for (size_t g = 0; g < r->parts.size(); g++)
+      if (chunk >= r->part_chunk0[g] && chunk < r->part_chunk0[g] + r->parts[g]->k) { owner = r->parts[g].get(); chunk -= r->part_chunk0[g]; break; }
+    owner->tables();
+    export_chunk(*owner, chunk, owner->arena.ptr(), nullptr, &out->array);
   } catch (const DecodeError&) {
     return RH_ERR_DECODE;
   } catch (...) {

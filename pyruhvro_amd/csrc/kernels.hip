@@ -363,21 +363,25 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P,
 // between two calls cost the GPU 5.7 us of idle time per call (profiles/r03aj_timeline.txt), and the spin sees the
 // token ~3 us sooner than hipStreamSynchronize returns (tools/synclat.hip).
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t head_words,
-                                                                 uint32_t null_entries, uint32_t flag_word, uint32_t token) {
+                                                                 uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots) {
   for (uint32_t i = threadIdx.x; i < head_words; i += kBlock) {      // control words + chunk totals, as they are
     host[i] = ctrl[i];
     ctrl[i] = 0;
   }
-  uint32_t* slots = ctrl + head_words;                               // [null_entries][kNullSlots]
+  uint32_t* slots = ctrl + head_words;                               // [null_entries][nslots] (program.h null_slots_for)
   for (uint32_t e = threadIdx.x; e < null_entries; e += kBlock) {
-    const v4w* p = reinterpret_cast<const v4w*>(slots + (size_t)e * kNullSlots);
     uint32_t sum = 0;
+    if (nslots == (uint32_t)kNullSlots) {
+      const v4w* p = reinterpret_cast<const v4w*>(slots + (size_t)e * kNullSlots);
 #pragma unroll
-    for (int q = 0; q < kNullSlots / 4; q++) { const v4w x = p[q]; sum += x.x + x.y + x.z + x.w; }
+      for (int q = 0; q < kNullSlots / 4; q++) { const v4w x = p[q]; sum += x.x + x.y + x.z + x.w; }
+    } else {
+      for (uint32_t q = 0; q < nslots; q++) sum += slots[(size_t)e * nslots + q];
+    }
     host[head_words + e] = sum;
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < null_entries * (uint32_t)kNullSlots; i += kBlock) slots[i] = 0;
+  for (uint32_t i = threadIdx.x; i < null_entries * nslots; i += kBlock) slots[i] = 0;
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(host + flag_word, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -460,7 +464,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   report_errors(P, s.misc, L, g, tid, blockIdx.x);   // barrier inside: nullcnt + staging complete
   for (int i = tid; i < P.nnodes; i += kBlock) {
     const uint32_t v = s.nullcnt[i];
-    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * kNullSlots + (blockIdx.x & (kNullSlots - 1))], v);
+    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * P.null_slots + (blockIdx.x & (P.null_slots - 1))], v);
   }
 }
 
@@ -492,9 +496,9 @@ extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, cons
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token,
-                                 void* stream) {
+                                 uint32_t nslots, void* stream) {
   hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, head_words,
-                     null_entries, flag_word, token);
+                     null_entries, flag_word, token, nslots);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {

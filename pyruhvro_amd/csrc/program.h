@@ -17,6 +17,12 @@ typedef unsigned long uintptr_t;
 #include <stdint.h>
 #endif
 
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#define RH_HD __host__ __device__
+#else
+#define RH_HD
+#endif
+
 namespace rh {
 
 constexpr int kBlock = 256;          // threads (= records) per workgroup
@@ -29,6 +35,14 @@ constexpr int kMaxUnionDepth = 8;    // nested N-variant unions (8-bit selector 
 // emit kernel took 0.476 ms with them and 0.200 ms without, profiles/r03ag_nullcount_slots_ab.txt), so every
 // (node, chunk) count is spread over kNullSlots addresses by tile index and summed on the host.
 constexpr int kNullSlots = 64;
+// Slots a call really uses: the control block is nnodes x k x slots words, device side and again in pinned memory, and the
+// reference lets num_chunks go up to n -- with many chunks the per-chunk workgroup count (and with it the contention a
+// slot relieves) falls as fast as the block grows, so the slot count is scaled down with k (a power of two, >= 1).
+RH_HD inline uint32_t null_slots_for(uint32_t k) {
+  uint32_t s = kNullSlots;
+  while (s > 1 && (uint64_t)s * k > 4096) s >>= 1;
+  return s;
+}
 
 enum FixedKind : int32_t { FK_I32 = 0, FK_I64 = 1, FK_F32 = 2, FK_F64 = 3, FK_BOOL = 4 };
 
@@ -105,12 +119,6 @@ struct BufDesc {
   int32_t counter;  // BK_DATA: counter id giving its byte length | BK_FIXW: bytes per row
   int32_t node;
 };
-
-#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
-#define RH_HD __host__ __device__
-#else
-#define RH_HD
-#endif
 
 // Arena slot of one Arrow buffer of one chunk: `alloc` bytes are reserved (exact Arrow size, bitmaps rounded up to
 // whole 64-bit words so a wavefront's ballot store never leaves the slot), `exact` is the Arrow size.  ONE statement of
@@ -189,11 +197,12 @@ struct KParams {
   unsigned long long* first_bad;  // control words (see LayoutFlag): [0] = ~(lowest failing record index), 0 if none (atomicMax)
   ErrInfo* errinfo;          // [nblocks]
   void* const* bufptr;       // [k][nbuf]
-  uint32_t* nullcount;       // [nnodes][k][kNullSlots]: a workgroup adds into slot (tile & (kNullSlots - 1)); the host sums the slots
+  uint32_t* nullcount;       // [nnodes][k][null_slots]: a workgroup adds into slot (tile & (null_slots - 1)); rh_k_publish / the host sum the slots
   // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
   uint32_t* lanecnt;         // [nblocks*TILE][ceil(K/2)] per-record counters, 16 bits each (saturated at 0xFFFF), record-major
   uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
+  uint32_t null_slots;       // null_slots_for(k): a power of two <= kNullSlots
   uint32_t all_careful;      // 1: no size pass classified the tiles (schemas without variable-length output): the emit kernel walks every tile carefully
 };
 

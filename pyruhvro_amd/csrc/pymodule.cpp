@@ -98,6 +98,11 @@ PyObject* stats_dict(const rh_stats& st) {
                        "total_ms", st.total_ms, "specialized", st.specialized, "lds_bytes", st.lds_bytes);
 }
 
+// Phase split of the calling thread's most recent decode() (last_decode_profile(); PYRUHVRO_PYPROF=1 prints the same line):
+// milliseconds of set-up, of the list extraction, of the rest of the call, and of the call's time with the GIL held.
+struct DecodeProfile { double n = 0, streaming = 0, alloc = 0, extract = 0, tail = 0, total = 0, gil_held = 0; };
+thread_local DecodeProfile g_last_profile;
+
 // decode(capsule, list, num_chunks, device=-1, stream=0, want_stats=False, kernel=0, devices=None)
 //   devices: None, or a sequence of HIP device ordinals to shard the chunks over (rh_opts.devices)
 //   -> (list[int] addresses of malloc'd ArrowArray structs, stats dict | None)
@@ -132,7 +137,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   static const bool pyprof = [] { const char* e = std::getenv("PYRUHVRO_PYPROF"); return e && *e && *e != '0'; }();
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-  double ms_alloc = 0, ms_extract = 0, ms_tail = 0;
+  double ms_alloc = 0, ms_extract = 0, ms_tail = 0, ms_released = 0;
   (void)ms_alloc;
   // one (pointer, length) per record, uninitialised (2 x 8 bytes x n): every slot is written below.  A reference is
   // held on every bytes object while the GIL is released; the object is recovered from its payload pointer afterwards
@@ -152,6 +157,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   ArrowArray* chunks = (ArrowArray*)std::calloc(k, sizeof(ArrowArray));
   rh_opts opts;
   std::memset(&opts, 0, sizeof opts);
+  opts.struct_size = (uint32_t)sizeof opts;
   opts.device = device;
   opts.flags = kernel;
   opts.stream = (void*)(uintptr_t)stream;
@@ -177,6 +183,16 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     return e && *e ? std::atol(e) : 65536l;
   }();
   bool streaming = stream_min >= 0 && (long)n >= stream_min && n >= 2 && stream == 0;
+#ifdef Py_GIL_DISABLED
+  streaming = false;      // free-threaded CPython: holding "the GIL" protects nothing, so objects are never borrowed without a reference
+#endif
+  // "-1 = the current device" means the CALLER's current device (torch.cuda.set_device / hipSetDevice are per host
+  // thread): the streaming form runs the engine on a thread of its own, where the current device would be 0 again, so
+  // the ordinal is resolved here, on the calling thread, before that thread exists.
+  if (streaming && opts.device < 0 && devices.empty()) {
+    const int cur = rh_current_device();
+    if (cur >= 0) opts.device = cur;
+  }
   std::atomic<uint64_t> ready{0}, gathered{0};
   std::atomic<bool> finished{false};
   std::thread worker;
@@ -205,7 +221,20 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     constexpr Py_ssize_t kBlk = 16384;
     const Py_ssize_t nblk = (n + kBlk - 1) / kBlk;
     const unsigned nth = (unsigned)std::max<long>(1, std::min<long>({8l, (long)std::thread::hardware_concurrency() / 4, (long)nblk}));
-    std::unique_ptr<std::atomic<unsigned char>[]> blk_done(new std::atomic<unsigned char>[(size_t)nblk]);
+    std::unique_ptr<std::atomic<unsigned char>[]> blk_done;
+    try {
+      blk_done.reset(new std::atomic<unsigned char>[(size_t)nblk]);
+    } catch (const std::bad_alloc&) {                 // the engine thread is running: tell it to give up, join it, then report
+      ready.store(~0ull, std::memory_order_release);
+      Py_BEGIN_ALLOW_THREADS
+      worker.join();
+      Py_END_ALLOW_THREADS
+      for (uint32_t c = 0; c < k; c++)
+        if (chunks[c].release) chunks[c].release(&chunks[c]);
+      if (err) rh_free_string(err);
+      std::free(chunks);
+      return PyErr_NoMemory();
+    }
     for (Py_ssize_t b = 0; b < nblk; b++) blk_done[(size_t)b].store(0, std::memory_order_relaxed);
     std::atomic<Py_ssize_t> first_bad{n};
     PyObject** items = PySequence_Fast_ITEMS(list);          // (a list: its item array, stable while the GIL is held)
@@ -267,9 +296,11 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     // the GIL stays with this thread until the engine has copied every record (or gave up): then nothing borrowed is in use
     while (!finished.load(std::memory_order_acquire) && gathered.load(std::memory_order_acquire) < (uint64_t)n)
       std::this_thread::sleep_for(std::chrono::microseconds(20));
+    const auto t_rel = std::chrono::steady_clock::now();
     Py_BEGIN_ALLOW_THREADS
     worker.join();
     Py_END_ALLOW_THREADS
+    ms_released = ms_since(t_rel);
     done = n;
   } else {
     // The list's objects are scattered over the heap: one cache miss per header.  The pointer array is contiguous, so
@@ -299,12 +330,19 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     }
     ms_extract = ms_since(t_extract);
     t_tail = std::chrono::steady_clock::now();
+    const auto t_rel = std::chrono::steady_clock::now();
     Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
     rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
     Py_END_ALLOW_THREADS
+    ms_released = ms_since(t_rel);
     drop_range(0, n);
   }
   ms_tail = ms_since(t_tail);
+  {
+    DecodeProfile& pr = g_last_profile;
+    pr.n = (double)n; pr.streaming = streaming ? 1 : 0; pr.alloc = ms_alloc; pr.extract = ms_extract; pr.tail = ms_tail;
+    pr.total = ms_since(t_start); pr.gil_held = pr.total - ms_released;
+  }
   if (pyprof)
     std::fprintf(stderr, "[pyruhvro pyprof] n=%zd streaming=%d alloc+setup=%.2f extract=%.2f engine_tail+release=%.2f total=%.2f ms\n", n,
                  (int)streaming, ms_alloc, ms_extract, ms_tail, ms_since(t_start));
@@ -400,6 +438,14 @@ PyObject* py_release_array(PyObject*, PyObject* args) {
 
 PyObject* py_device_count(PyObject*, PyObject*) { return PyLong_FromLong(rh_device_count()); }
 
+// last_decode_profile() -> dict: phase milliseconds of this thread's most recent decode() (up to the point where the result
+// list is built), incl. the time the call held the GIL
+PyObject* py_last_decode_profile(PyObject*, PyObject*) {
+  const DecodeProfile& pr = g_last_profile;
+  return Py_BuildValue("{s:d,s:d,s:d,s:d,s:d,s:d,s:d}", "records", pr.n, "streaming", pr.streaming, "alloc_setup_ms", pr.alloc,
+                       "extract_ms", pr.extract, "engine_tail_release_ms", pr.tail, "total_ms", pr.total, "gil_held_ms", pr.gil_held);
+}
+
 PyMethodDef methods[] = {
     {"compile_schema", py_compile_schema, METH_VARARGS, "compile_schema(json) -> schema capsule"},
     {"schema_ptr", py_schema_ptr, METH_VARARGS, "schema_ptr(capsule) -> int (rh_schema*)"},
@@ -409,6 +455,7 @@ PyMethodDef methods[] = {
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
     {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},
+    {"last_decode_profile", py_last_decode_profile, METH_NOARGS, "phase milliseconds of this thread's most recent decode()"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pyruhvro", "ruhvro_hip CPython boundary", -1, methods,

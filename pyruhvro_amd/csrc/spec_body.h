@@ -425,7 +425,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
   // this record's counters as k_size left them (requested with the window, so no extra round trip)
-  const uint32_t tflag = P.all_careful ? 2u : P.tileflag[tile];
+  // (all_careful: no size pass classified the tiles -- K == 0, tileflag is not even written -- or RUHVRO_HIP_NO_TRUST;
+  //  a saturated counter, bit 0, still sends the tile through the re-size walk)
+  const uint32_t tflag = (S::K > 0 ? P.tileflag[tile] : 0u) | (P.all_careful ? 2u : 0u);
   const uint32_t rewalk = tflag & 1u;
   const bool careful = (tflag & 2u) != 0;
   if constexpr (S::K > 0) {
@@ -490,7 +492,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   for (int i = tid; i < S::NNODES; i += T) {
     uint32_t v = s.nullcnt[i];
     for (int w = 0; w < NW; w++) v += s.nullw[i * NW + w];
-    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * kNullSlots + (tile & (kNullSlots - 1))], v);
+    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * P.null_slots + (tile & (P.null_slots - 1))], v);
   }
   if constexpr (S::NB0 > 0) {   // the tile's domain-0 bitmap words (SCtx::put_word0): one lane per word
     for (uint32_t i = tid; i < (uint32_t)(S::NB0 * NW); i += T) {

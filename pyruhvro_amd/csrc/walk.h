@@ -690,14 +690,19 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
   uint32_t len = (uint32_t)op.b;
   if (has_len) {
     const bool neg = want && (CAREFUL ? v < 0 : (int32_t)v < 0);
-    const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)(L.end - L.cur) : (uint32_t)v > L.end - L.cur);
+    // bytes left in the record, 0 for a cursor that is already past its end: the fast size walk checks a record's bounds
+    // once, at its end (read_head), so its cursor may have run past L.end after an over-long string, and the unsigned
+    // difference would wrap and let the guards below pass -- these guards are what keeps the byte loops inside the window
+    const uint32_t left = (int32_t)(L.end - L.cur) < 0 && !CAREFUL ? 0u : L.end - L.cur;
+    const bool eob = want && !neg && (CAREFUL ? (uint64_t)v > (uint64_t)left : (uint32_t)v > left);
     RH_REJECT(L, neg, E_NEGLEN);
     RH_REJECT(L, eob, E_EOB_STR);
     len = (want && L.live) ? (uint32_t)v : 0u;
     if (op.a == BN_DEC_BYTES) RH_REJECT(L, want && L.live && len > 16u, E_DECIMAL, (int64_t)len);
     if (op.a == BN_UUID_STR) RH_REJECT(L, want && L.live && len != 36u && len != 32u, E_UUID);
   } else {
-    RH_REJECT(L, want && (L.end - L.cur) < len, E_EOB_FIXED);
+    const uint32_t left = (int32_t)(L.end - L.cur) < 0 && !CAREFUL ? 0u : L.end - L.cur;      // (see above)
+    RH_REJECT(L, want && left < len, E_EOB_FIXED);
   }
   bool valid = want && L.live;
   const uint32_t spos = L.cur;

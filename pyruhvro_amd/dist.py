@@ -60,7 +60,7 @@ def max_over_ranks(value: float, device) -> float:
     import torch
     import torch.distributed as dist
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():                  # (a one-rank group too: bench.py BENCH_FORCE_DIST runs the real collectives on one GPU)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -70,7 +70,7 @@ def gather_stats(local: Dict[str, float], device) -> List[Dict[str, float]]:
     import torch
     import torch.distributed as dist
     v = torch.tensor([float(local.get(k, 0.0)) for k in STAT_KEYS], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         outs = [torch.zeros_like(v) for _ in range(dist.get_world_size())]
         dist.all_gather(outs, v)
     else:

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--fast-only", action="store_true")
     ap.add_argument("--lines", type=int, default=0, help="also print the N hottest source lines")
     ap.add_argument("--opcode", default="", help="also print the source lines that emit this opcode (e.g. v_lshl_add_u64)")
+    ap.add_argument("--keep-asm", default="", help="copy the kernel's annotated assembly (.s) to this path")
     ap.add_argument("--variant", default="", help="RUHVRO_HIP_VARIANT names (staged experimental code paths), comma separated")
     args = ap.parse_args()
     if args.variant:
@@ -78,6 +79,9 @@ def main():
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-gline-tables-only", "-I", tmp,
                                "--cuda-device-only", "-S", os.path.join(tmp, "k.hip"), "-o", asm])
         lines = open(asm).read().split("\n")
+        if args.keep_asm:
+            shutil.copy(asm, args.keep_asm)
+            shutil.copy(os.path.join(tmp, "k.hip"), args.keep_asm + ".hip")
         ranges = {h: function_ranges(os.path.join(tmp, h)) for h in HEADERS}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
