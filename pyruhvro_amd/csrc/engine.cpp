@@ -824,7 +824,8 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
   try {
     // in-call overlap (decode_device_split): a large call deals its chunk groups to internal streams
     const long G = env_long("RUHVRO_HIP_INTERNAL_STREAMS", kInternalStreamsDefault, 1, 8);
-    if (G > 1 && !geo && !stats && n >= (uint64_t)env_long("RUHVRO_HIP_SPLIT_MIN", kSplitMinDefault, 1, 1l << 40) &&
+    const long groups_env = env_long("RUHVRO_HIP_SPLIT_GROUPS", 0, 0, 64);      // (> 1 with one stream: the groups run back to back)
+    if ((G > 1 || groups_env > 1) && !geo && !stats && n >= (uint64_t)env_long("RUHVRO_HIP_SPLIT_MIN", kSplitMinDefault, 1, 1l << 40) &&
         (!opts || (opts->flags & 3) != RH_KERNEL_GENERIC) && s->arena_ratio.load() > 0 && env_long("RUHVRO_HIP_TWO_SYNC", 0, 0, 1) == 0 &&
         env_long("RUHVRO_HIP_ARENA_PERMILLE", -1, 0, 1000000) < 0) {
       const rh_opts o = opts ? *opts : default_opts();
@@ -836,7 +837,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
         k64 = num_chunks; sz = o.chunk_rows;
       }
       const unsigned g = (unsigned)std::min<uint64_t>((uint64_t)G, k64);
-      if (ok && g > 1 && !((uintptr_t)d_data & 15)) {
+      if (ok && (g > 1 || (groups_env > 1 && k64 > 1)) && !((uintptr_t)d_data & 15)) {
         const uint64_t rows_last = n - (k64 - 1) * sz;
         try {
           if (rh_device_result* r = decode_device_split(s, d_data, d_offsets, data_len, n, o, (uint32_t)k64, sz, rows_last, g)) return r;
@@ -1747,6 +1748,30 @@ Gathered gather_slices(const Source& src, uint64_t r0, uint64_t n, int device, u
   return g;
 }
 
+// rh_bench_gather (test hook): the two passes of gather_slices over rows [r0, r0 + n) into a destination the caller
+// provides -- what bounds the HOST side of a g-GPU call, measurable without g GPUs.  Returns the payload bytes.
+uint64_t gather_into(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, unsigned nt_in, uint8_t* hdst, uint64_t* hoff) {
+  const unsigned nt = n >= 4096 ? std::max(1u, nt_in) : 1u;
+  auto lo_of = [&](unsigned t) { return n * t / nt; };
+  std::vector<uint64_t> part(nt + 1, 0);
+  run_threads(nt, [&](unsigned t) {
+    uint64_t sum = 0;
+    for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) sum += lens[i];
+    part[t + 1] = sum;
+  });
+  for (unsigned t = 0; t < nt; t++) part[t + 1] += part[t];
+  run_threads(nt, [&](unsigned t) {
+    uint64_t pos = part[t];
+    for (uint64_t i = lo_of(t); i < lo_of(t + 1); i++) {
+      hoff[i] = pos;
+      std::memcpy(hdst + pos, ptrs[i], lens[i]);
+      pos += lens[i];
+    }
+  });
+  hoff[n] = part[nt];
+  return part[nt];
+}
+
 // Rows [r0, r0 + n) of a PACKED source in pageable memory, copied into pooled PINNED memory by the call's host
 // threads in the layout of the device staging buffer (one H2D copy then takes the whole range).  The runtime stages a
 // pageable H2D copy through its own bounce buffers on the calling thread, and such copies do not overlap with another
@@ -2211,6 +2236,45 @@ int rh_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// Test / measurement hook (not part of the drop-in surface): `shards` host threads gather their contiguous share of the n
+// record slices at the same time, each with `threads_per_shard` helpers, exactly as the shards of a multi-GPU rh_decode
+// call do (gather_slices) -- into pageable memory (pinned = 0; needs no GPU) or pinned memory (pinned = 1).  Destinations
+// are allocated and touched before the clock starts.  Writes the best wall time of `reps` rounds to *best_ms and returns
+// the payload bytes gathered per round (0 on failure).
+uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint32_t shards, uint32_t threads_per_shard,
+                         int pinned, uint32_t reps, double* best_ms) {
+  if (!ptrs || !lens || !best_ms || shards == 0) return 0;
+  struct Dst { uint8_t* p = nullptr; uint64_t bytes = 0, rows0 = 0, rows = 0, o_off = 0; };
+  std::vector<Dst> dst(shards);
+  uint64_t total = 0;
+  bool ok = true;
+  for (uint32_t j = 0; j < shards; j++) {
+    Dst& d = dst[j];
+    d.rows0 = n * j / shards; d.rows = n * (j + 1) / shards - d.rows0;
+    uint64_t b = 0;
+    for (uint64_t i = 0; i < d.rows; i++) b += lens[d.rows0 + i];
+    total += b;
+    d.o_off = align_up(16 + b + 32, kAlign);
+    d.bytes = d.o_off + 8 * (d.rows + 1);
+    if (pinned) ok = ok && hipHostMalloc((void**)&d.p, d.bytes, hipHostMallocDefault) == hipSuccess;
+    else ok = ok && posix_memalign((void**)&d.p, 4096, d.bytes) == 0;
+    if (ok) std::memset(d.p, 0, d.bytes);
+  }
+  double best = 1e30;
+  for (uint32_t r = 0; ok && r < std::max(reps, 1u); r++) {
+    Timer t;
+    run_threads(shards, [&](unsigned j) {
+      Dst& d = dst[j];
+      gather_into(ptrs + d.rows0, lens + d.rows0, d.rows, threads_per_shard, d.p + 16, (uint64_t*)(d.p + d.o_off));
+    });
+    best = std::min(best, (double)t.ms());
+  }
+  for (Dst& d : dst)
+    if (d.p) { if (pinned) (void)hipHostFree(d.p); else std::free(d.p); }
+  *best_ms = best;
+  return ok ? total : 0;
 }
 
 int rh_current_device(void) {

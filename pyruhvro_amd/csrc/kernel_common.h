@@ -53,6 +53,22 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t nblocks) 
 // (k_emit 0.950 -> 0.940 ms, profiles/r02a_variants_ab.txt).
 template <int TILE, int ROWS>
 __device__ __forceinline__ void stage_exact(const RH_GLOBAL v4u* gp, v4u* lp, uint32_t rem, uint32_t tid) {
+#ifndef RH_V_NODMA
+  // The rows are moved by LDS-DMA -- global_load_lds_dwordx4: 1 KiB per wave instruction, destination = a wave-uniform
+  // LDS base (M0) + lane x 16 -- with no VGPR round trip and no ds_write_b128 (13 LDS cycles each, eight per thread: 16 %
+  // of the size kernel's LDS instructions): k_size -3.4 %, k_emit -1 % (profiles/r04g_lds_dma_ab.txt; RH_V_NODMA = the
+  // register path below, kept for the A/B).  stage_window waits vmcnt(0) for them in front of the workgroup barrier.
+  {
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    RH_LDS uint8_t* const lw = (RH_LDS uint8_t*)(lp - tid) + wave * 1024u;                 // this wavefront's 1 KiB of row 0
+    const RH_GLOBAL uint8_t* const g0 = reinterpret_cast<const RH_GLOBAL uint8_t*>(gp);    // this lane's 16 bytes of row 0
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      __builtin_amdgcn_global_load_lds(g0 + (size_t)j * (TILE * 16u), lw + j * (TILE * 16), 16, 0, 0);
+    if (tid < rem) __builtin_amdgcn_global_load_lds(g0 + (size_t)ROWS * (TILE * 16u), lw + ROWS * (TILE * 16), 16, 0, 0);
+    return;
+  }
+#endif
   // uniform base + 32-bit lane offset: the loads take the scalar-base addressing form, one v_add per row
   const uintptr_t base = reinterpret_cast<uintptr_t>(gp - tid);
   const uint32_t voff = tid * 16u;
@@ -108,6 +124,9 @@ __device__ __forceinline__ void stage_window(const KParams& P, uint8_t* win, uin
       done += left;
     }
   }
+#ifndef RH_V_NODMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA rows have landed before this wave reaches the barrier
+#endif
   if (nfull < nvec && tid < 16) {   // ragged tail of the payload: bytes, zero-filled past the end
     const uint64_t pos = wb16 + ((uint64_t)nfull << 4);
     win[(nfull << 4) + tid] = pos + tid < P.data_len ? P.data[pos + tid] : 0;

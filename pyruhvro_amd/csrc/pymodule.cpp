@@ -239,6 +239,22 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     std::atomic<Py_ssize_t> first_bad{n};
     PyObject** items = PySequence_Fast_ITEMS(list);          // (a list: its item array, stable while the GIL is held)
     std::atomic<Py_ssize_t> next_blk{0};
+    // `ready` follows the prefix of finished blocks WHILE the blocks are extracted: whoever finishes a block advances the
+    // prefix as far as it goes (round 3 published it only after the calling thread had run out of blocks to claim, i.e.
+    // at the end of the extraction -- the engine's first gather then started when the last entry was there, and nothing
+    // of the extraction overlapped the copies: 10M records 58.9 -> see profiles/r04j_python_surface.txt)
+    std::atomic<Py_ssize_t> prefix{0};
+    auto publish = [&]() {
+      for (;;) {
+        Py_ssize_t p = prefix.load(std::memory_order_acquire);
+        if (p >= nblk || !blk_done[(size_t)p].load(std::memory_order_acquire)) return;
+        if (!prefix.compare_exchange_strong(p, p + 1, std::memory_order_acq_rel)) continue;       // another thread moved it
+        const Py_ssize_t bad = first_bad.load(std::memory_order_relaxed);
+        const uint64_t upto = (uint64_t)std::min<Py_ssize_t>(std::min<Py_ssize_t>((p + 1) * kBlk, n), bad);
+        uint64_t cur = ready.load(std::memory_order_relaxed);
+        while (cur < upto && !ready.compare_exchange_weak(cur, upto, std::memory_order_release)) {}   // monotonic
+      }
+    };
     auto extract = [&]() {
       for (Py_ssize_t b; (b = next_blk.fetch_add(1, std::memory_order_relaxed)) < nblk;) {
         const Py_ssize_t lo = b * kBlk, hi = std::min<Py_ssize_t>(lo + kBlk, n);
@@ -259,6 +275,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
           }
         }
         blk_done[(size_t)b].store(1, std::memory_order_release);
+        publish();
       }
     };
     std::vector<std::thread> helpers;
@@ -267,13 +284,9 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     } catch (const std::system_error&) {}            // fewer helpers: the blocks are claimed dynamically
     // this thread takes its share too, then follows the prefix of finished blocks
     extract();
-    Py_ssize_t prefix = 0;
-    for (;;) {
-      while (prefix < nblk && blk_done[(size_t)prefix].load(std::memory_order_acquire)) prefix++;
-      const Py_ssize_t bad = first_bad.load(std::memory_order_relaxed);
-      const Py_ssize_t upto = std::min<Py_ssize_t>(std::min<Py_ssize_t>(prefix * kBlk, n), bad);
-      ready.store((uint64_t)upto, std::memory_order_release);
-      if (prefix == nblk || bad < n) break;
+    for (;;) {                                        // (the helpers' last blocks)
+      publish();
+      if (prefix.load(std::memory_order_acquire) == nblk || first_bad.load(std::memory_order_relaxed) < n) break;
       std::this_thread::yield();
     }
     for (auto& h : helpers) h.join();

@@ -61,11 +61,12 @@ constexpr int kDenseCap = 128;    // item positions per wavefront and round of t
 template <class S>
 struct SCtx {
   static constexpr int K1 = S::K > 0 ? S::K : 1;
+  static constexpr int KP = (K1 + 3) & ~3;           // words per wavefront row of wtot
   static constexpr bool kWide = false;   // 32-bit byte offsets into each buffer (host guards: buffers < 4 GiB per chunk)
   static constexpr bool kSkip = false;
   static constexpr bool kDense = S::NDENSE > 0;
   uint32_t* dtab;                                     // LDS [kDenseCap]: this wavefront's item-position table (dense_list)
-  const uint32_t* wtot_w;                             // LDS: wtot[k * NW + this wave] = this wavefront's total of counter k
+  const uint32_t* wtot_w;                             // LDS: this wavefront's row of wtot: wtot_w[k] = its total of counter k
   mutable uint32_t cnt[K1];                           // per-lane counters (registers)
   mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
   // this chunk's row of the buffer-address table.  Read-only for the whole launch, so it is addressed through the
@@ -160,10 +161,10 @@ __device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[
   }
 }
 
-// LDS in front of the window: wtot[K][NW] | nullcnt[NNODES] | nullw[NNODES][NW] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
+// LDS in front of the window: wtot[NW][KP] (KP = K rounded up to 4: a wavefront's totals are one contiguous, 16-byte aligned row) | nullcnt[NNODES] | nullw[NNODES][NW] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
 // a dense list) | bmw0[NB0][NW] u64   (host mirror: spec_lds_fixed_words_host)
 __host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
-  return (((uint32_t)(K > 0 ? K : 1) * (uint32_t)nw + 3) & ~3u) + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
+  return (((uint32_t)(K > 0 ? K : 1) + 3) & ~3u) * (uint32_t)nw + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
          (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
 }
 
@@ -187,7 +188,7 @@ struct SpecSmem {
   uint8_t* win;
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
-    wtot = p; p += ((S::K > 0 ? S::K : 1) * (S::TILE / 64) + 3) & ~3;
+    wtot = p; p += (((S::K > 0 ? S::K : 1) + 3) & ~3) * (S::TILE / 64);
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
     nullw = p; p += ((S::NNODES * (S::TILE / 64) + 3) & ~3);
     misc = p; p += 4;
@@ -217,7 +218,7 @@ template <class S, int LID, int D, int DEPTH, class Src, class Body>
 __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lane& L, Body&& body) {
   constexpr int NW = S::TILE / 64;
   uint32_t* const tab = c.dtab;
-  const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.wtot_w[D * NW]);   // items of this wavefront
+  const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.wtot_w[D]);   // items of this wavefront
   const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cnt[D]);         // tile-local row of its first item
   uint32_t carry[SCtx<S>::K1];                               // running tile-local byte offset of the body's string columns
   static_for<0, S::K>([&](auto ik) {
@@ -307,7 +308,7 @@ __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, cons
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
   c.nullcnt = s.nullcnt; c.nullw_w = s.nullw + (tid >> 6); c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
-  c.dtab = s.dtab + (tid >> 6) * kDenseCap; c.wtot_w = s.wtot + (tid >> 6);
+  c.dtab = s.dtab + (tid >> 6) * kDenseCap; c.wtot_w = s.wtot + (tid >> 6) * SCtx<S>::KP;
   c.bmw0 = s.bmw0;
 }
 
@@ -320,7 +321,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
-  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW;
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW, KP = SCtx<S>::KP;
   const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
   const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
@@ -371,15 +372,15 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
       constexpr int d = decltype(id)::value;
       const uint32_t v = wave_sum(packed[d]);
       if (lane == 0) {
-        s.wtot[(2 * d) * NW + wave] = v & 0xFFFFu;
-        if constexpr (2 * d + 1 < S::K) s.wtot[(2 * d + 1) * NW + wave] = v >> 16;
+        s.wtot[wave * KP + 2 * d] = v & 0xFFFFu;
+        if constexpr (2 * d + 1 < S::K) s.wtot[wave * KP + 2 * d + 1] = v >> 16;
       }
     });
   } else {
     static_for<0, S::K>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
       const uint32_t v = wave_sum(c.cnt[k]);
-      if (lane == 0) s.wtot[k * NW + wave] = v;
+      if (lane == 0) s.wtot[wave * KP + k] = v;
     });
   }
   if constexpr (S::K > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
@@ -389,7 +390,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   if (tid == 0) P.tileflag[tile] = s.misc[2];
   for (int k = tid; k < S::K; k += T) {
     uint32_t tsum = 0;
-    for (int w = 0; w < NW; w++) tsum += s.wtot[k * NW + w];
+    for (int w = 0; w < NW; w++) tsum += s.wtot[w * KP + k];
     P.blocksum[(size_t)k * P.nblocks + tile] = tsum;
   }
   RH_MARK(19);
@@ -409,7 +410,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const SpecSmem<S> s(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
-  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW;
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW, KP = SCtx<S>::KP;
   const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
   const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
@@ -430,15 +431,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const uint32_t tflag = (S::K > 0 ? P.tileflag[tile] : 0u) | (P.all_careful ? 2u : 0u);
   const uint32_t rewalk = tflag & 1u;
   const bool careful = (tflag & 2u) != 0;
-  if constexpr (S::K > 0) {
-    constexpr int NDW = (S::K + 1) / 2;
-    uint32_t packed[NDW];
-    lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
-    static_for<0, S::K>([&](auto ik) {
-      constexpr int k = decltype(ik)::value;
-      c.cnt[k] = (k & 1) ? packed[k / 2] >> 16 : packed[k / 2] & 0xFFFFu;
-    });
-  }
+  constexpr int NDW = (S::K + 1) / 2;
+  uint32_t packed[NDW > 0 ? NDW : 1] = {};      // two 16-bit counters per dword, as k_size left them (unpacked after the scan)
+  if constexpr (S::K > 0) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);
@@ -451,30 +446,66 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   RH_MARK(1);
 
   if (S::K > 0) {
+    bool narrow = !rewalk;
     if (rewalk) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
       static_for<0, S::K>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
       lane_init_from(L, g, o0, o1, wb16, tid);
       spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
+    } else {
+      // every counter of the wave below 1024: the inclusive scan of a PACKED dword cannot carry from its low half into
+      // its high half (64 x 1023 < 2^16), so the wave scans two counters per dword -- half the DPP adds
+      uint32_t allor = 0;
+      static_for<0, NDW>([&](auto id) { allor |= packed[decltype(id)::value]; });
+      narrow = !__any((allor & 0xFC00FC00u) != 0);
+      if (!narrow) static_for<0, S::K>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        c.cnt[k] = (k & 1) ? packed[k / 2] >> 16 : packed[k / 2] & 0xFFFFu;
+      });
     }
     RH_MARK(3);
-    static_for<0, S::K>([&](auto ik) {
-      constexpr int k = decltype(ik)::value;
-      const uint32_t v = c.cnt[k];
-      const uint32_t incl = wave_incl_scan(v, lane);
-      if (lane == 63) s.wtot[k * NW + wave] = incl;
-      c.cnt[k] = incl - v;
-    });
+    if (narrow) {
+      uint32_t tot[SCtx<S>::KP] = {};
+      static_for<0, NDW>([&](auto id) {
+        constexpr int d = decltype(id)::value;
+        const uint32_t v = packed[d];
+        const uint32_t incl = wave_incl_scan(v, lane);
+        const uint32_t ex = incl - v;
+        c.cnt[2 * d] = ex & 0xFFFFu;
+        tot[2 * d] = incl & 0xFFFFu;
+        if constexpr (2 * d + 1 < S::K) { c.cnt[2 * d + 1] = ex >> 16; tot[2 * d + 1] = incl >> 16; }
+      });
+      if (lane == 63) {      // this wavefront's totals: one contiguous row (16-byte stores)
+        static_for<0, SCtx<S>::KP / 4>([&](auto iq) {
+          constexpr int q = decltype(iq)::value;
+          v4w x; x.x = tot[4 * q]; x.y = tot[4 * q + 1]; x.z = tot[4 * q + 2]; x.w = tot[4 * q + 3];
+          *reinterpret_cast<v4w*>(s.wtot + wave * KP + 4 * q) = x;
+        });
+      }
+    } else {
+      static_for<0, S::K>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        const uint32_t v = c.cnt[k];
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s.wtot[wave * KP + k] = incl;
+        c.cnt[k] = incl - v;
+      });
+    }
     RH_MARK(4);
     __syncthreads();
     RH_MARK(5);
-    static_for<0, S::K>([&](auto ik) {   // workgroup-local exclusive prefix
-      constexpr int k = decltype(ik)::value;
-      if constexpr (NW > 1) {
-        uint32_t pre = 0;
-        for (int w = 0; w < NW - 1; w++) pre += (int)wave > w ? s.wtot[k * NW + w] : 0u;
-        c.cnt[k] += pre;
+    if constexpr (NW > 1) {
+      // workgroup-local exclusive prefix.  Lane k sums counter k's totals of the wavefronts in front of this one (three
+      // LDS reads at most); every lane then takes counter k's sum from lane k with v_readlane: 2 VALU per counter, not
+      // the 5-6 of selecting and adding NW - 1 broadcast totals per counter in every lane
+      uint32_t prev = 0;
+      if (lane < (uint32_t)S::K) {
+        for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + lane] : 0u;
       }
-    });
+      static_for<0, S::K>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        c.cnt[k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+      });
+    }
   }
 
   RH_MARK(6);

@@ -99,6 +99,12 @@ struct LdsSrc {
     const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
     return ((uint64_t)hi << 32) | lo;
   }
+  // copy8_pieces: the aligned dword that holds byte p, and the two aligned dwords behind byte p + j (j a multiple of 4)
+  __device__ __forceinline__ uint32_t ld4a(uint32_t p) const { return *reinterpret_cast<const uint32_t*>(w + (p & ~3u)); }
+  __device__ __forceinline__ void next2(uint32_t p, int j, uint32_t& d1, uint32_t& d2) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    d1 = a[j / 4 + 1]; d2 = a[j / 4 + 2];
+  }
 };
 
 // The same window, addressed ABSOLUTELY: positions are LDS byte addresses (the window's own LDS address is added to
@@ -142,6 +148,11 @@ struct LdsAbsSrc {
     const uint32_t hi = __builtin_amdgcn_alignbyte(0u, d1, sh);
     return ((uint64_t)hi << 32) | lo;
   }
+  __device__ __forceinline__ uint32_t ld4a(uint32_t p) const { return dw(p)[0]; }
+  __device__ __forceinline__ void next2(uint32_t p, int j, uint32_t& d1, uint32_t& d2) const {
+    const RH_LDS uint32_t* a = dw(p);
+    d1 = a[j / 4 + 1]; d2 = a[j / 4 + 2];      // (ds_read2_b32 with immediate offsets off one address register)
+  }
 };
 
 struct GlobalSrc {
@@ -156,6 +167,13 @@ struct GlobalSrc {
   }
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
   __device__ __forceinline__ uint32_t ld4(uint32_t p) const { return (uint32_t)ld8(p); }
+  // (copy8_pieces over global memory: unaligned reads are fine here, so the "aligned dwords" are taken as if p & 3 were 0
+  //  -- the pieces' funnel shift is by p & 3, which callers of a GlobalSrc get right by reading at p - (p & 3))
+  __device__ __forceinline__ uint32_t ld4a(uint32_t p) const { return (uint32_t)ld8(p & ~3u); }
+  __device__ __forceinline__ void next2(uint32_t p, int j, uint32_t& d1, uint32_t& d2) const {
+    const uint64_t x = ld8((p & ~3u) + (uint32_t)j + 4u);
+    d1 = (uint32_t)x; d2 = (uint32_t)(x >> 32);
+  }
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
     const uint64_t lo = ld8(p), hi = ld8(p + 8);
     v4w r;
@@ -197,6 +215,13 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
   if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off) = v;
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
 }
+// the same at a compile-time distance behind `off`: the distance is added in 64 bits, AFTER the 32-bit offset is extended,
+// so it lands in the instruction's immediate offset field instead of costing a VALU add per store
+template <class T, bool WIDE, int IMM>
+__device__ __forceinline__ void st_at_imm(void* base, uint64_t off, T v) {
+  if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off + (uint64_t)IMM) = v;
+  else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint64_t)(uint32_t)off + (uint64_t)IMM) = v;
+}
 // byte offsets into a buffer: 64-bit when WIDE, else 32-bit END TO END -- an offset that is summed in 64 bits and
 // truncated at the store makes the compiler carry a zero-extended VGPR pair and add the base with a VALU instruction
 // (v_lshl_add_u64 + the `off` addressing form) instead of using the scalar-base form (72 VALU instructions of the emit
@@ -207,22 +232,63 @@ template <> struct BufOff<false> { typedef uint32_t type; };
 template <bool WIDE, class Src>
 __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len) {
   // A store instruction costs the CU's store path about (width x 64 lanes) / 18 cycles WHATEVER the number of active
-  // lanes (tools/storecost.hip), so a column whose lengths straddle 16 pays for the 16-byte class and the 8-byte class
-  // separately.  When the wave has a string of 8..15 bytes, every string of 8 bytes and more is written with 8-byte
-  // stores instead (the last one ending at the string's end, overlapping): ceil(maxlen / 8) fuller instructions
-  // (k_emit -1.5 %, profiles/r02i_variants_ab.txt).  Not when the wave also holds a long string: 16 bytes a store there.
-  if (__any(len >= 8 && len < 16) && !__any(len > 64)) {
-    if (len >= 8) {
-      uint32_t j = 0;
-      for (;;) {
-        const uint32_t off = j + 8 <= len ? j : len - 8;
-        st_at<u64u, WIDE>(base, d + off, s.ld8(sp + off));
-        j += 8;
-        if (j >= len) break;
+  // lanes (tools/storecost.hip): what a column costs that path is its bytes rounded up to pieces, whatever the piece.
+#ifndef RH_V_NOBATCH
+  // Strings of up to 40 bytes (every string of the wave): ALL window reads of the column's strings are issued before the
+  // first store -- the first 8 bytes, the last 8 bytes, and under wave-uniform tests the 8-byte pieces between -- so a string
+  // column costs ONE LDS round trip, where head piece, each further piece and the tail each waited for their own
+  // (the emit walk is bound by its dependent round trips at 16 waves per CU, not by instruction issue: 16 % fewer VALU
+  // instructions moved it 1.5 %, profiles/r04d_*).  Then whole 8-byte pieces at constant offsets + the last 8 bytes,
+  // overlapping; strings below 8 bytes by the set bits of their length.
+  if (!__any(len > 40u)) {
+    const uint32_t sh = sp & 3u;
+    uint32_t w0 = s.ld4a(sp), w1, w2, w3, w4, w5, w6, w7, w8, w9, w10;
+    // (pieces the wave does not reach are never stored: their registers just need A value, at no cost)
+    asm volatile("" : "=v"(w3), "=v"(w4), "=v"(w5), "=v"(w6), "=v"(w7), "=v"(w8), "=v"(w9), "=v"(w10));
+    s.next2(sp, 0, w1, w2);
+    const bool tail = len > 8u && (len & 7u) != 0;
+    const uint32_t tp = sp + (tail ? len - 8u : 0u);
+    uint32_t t0 = s.ld4a(tp), t1, t2;
+    s.next2(tp, 0, t1, t2);
+    if (__any(len >= 16u)) {
+      s.next2(sp, 8, w3, w4);
+      if (__any(len >= 24u)) {
+        s.next2(sp, 16, w5, w6);
+        if (__any(len >= 32u)) {
+          s.next2(sp, 24, w7, w8);
+          if (__any(len >= 40u)) s.next2(sp, 32, w9, w10);
+        }
       }
-      return;
     }
+    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh), x1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    if (len >= 8u) {
+      st_at<u64u, WIDE>(base, d, ((uint64_t)x1 << 32) | x0);
+      if (len >= 16u) {
+        st_at_imm<u64u, WIDE, 8>(base, d, ((uint64_t)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32) | __builtin_amdgcn_alignbyte(w3, w2, sh));
+        if (len >= 24u) {
+          st_at_imm<u64u, WIDE, 16>(base, d, ((uint64_t)__builtin_amdgcn_alignbyte(w6, w5, sh) << 32) | __builtin_amdgcn_alignbyte(w5, w4, sh));
+          if (len >= 32u) {
+            st_at_imm<u64u, WIDE, 24>(base, d, ((uint64_t)__builtin_amdgcn_alignbyte(w8, w7, sh) << 32) | __builtin_amdgcn_alignbyte(w7, w6, sh));
+            if (len >= 40u)
+              st_at_imm<u64u, WIDE, 32>(base, d, ((uint64_t)__builtin_amdgcn_alignbyte(w10, w9, sh) << 32) | __builtin_amdgcn_alignbyte(w9, w8, sh));
+          }
+        }
+      }
+      if (tail) {
+        const uint32_t tsh = tp & 3u;
+        st_at<u64u, WIDE>(base, d + (len - 8u), ((uint64_t)__builtin_amdgcn_alignbyte(t2, t1, tsh) << 32) | __builtin_amdgcn_alignbyte(t1, t0, tsh));
+      }
+    } else {
+      const uint64_t x = ((uint64_t)x1 << 32) | x0;
+      if (len & 4u) st_at<u32u, WIDE>(base, d, (uint32_t)x);
+      if (len & 2u) st_at<u16u, WIDE>(base, d + (len & 4u), (uint16_t)(x >> (8 * (len & 4u))));
+      if (len & 1u) st_at<uint8_t, WIDE>(base, d + (len & 6u), (uint8_t)(x >> (8 * (len & 6u))));
+    }
+    return;
   }
+#endif
+  // longer strings in the wave: 16-byte pieces (two window reads in flight per round), 8..15 bytes as two overlapping
+  // 8-byte stores, shorter ones by the set bits of their length
   if (len >= 16) {
     uint32_t j = 0;
     for (; j + 32 <= len; j += 32) {
