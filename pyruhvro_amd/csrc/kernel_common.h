@@ -141,7 +141,7 @@ __device__ __forceinline__ void lane_init_from(Lane& L, const Geo& g, uint64_t o
   L.err = 0;
   L.edetail = 0;
   L.redo = false;
-  L.pstk = 0; L.lstk = 0; L.sstk = 0;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0; L.la = 0;
   L.cur = L.live ? (uint32_t)(o0 - wb16) : 0;
   L.end = L.live ? (uint32_t)(o1 - wb16) : 0;
 }
@@ -152,7 +152,7 @@ __device__ __forceinline__ void lane_init(Lane& L, const KParams& P, const Geo& 
   L.err = 0;
   L.edetail = 0;
   L.redo = false;
-  L.pstk = 0; L.lstk = 0; L.sstk = 0;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0; L.la = 0;
   L.cur = 0; L.end = 0;
   if (L.live) {
     const uint64_t o0 = P.offsets[g.rec0 + tid], o1 = P.offsets[g.rec0 + tid + 1];

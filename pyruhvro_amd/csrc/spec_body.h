@@ -255,7 +255,7 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
       const bool act = i < nr;
       Lane Li;
       Li.live = act; Li.pres = act; Li.err = 0; Li.edetail = 0; Li.redo = false;
-      Li.pstk = 0; Li.lstk = 0; Li.sstk = 0;
+      Li.pstk = 0; Li.lstk = 0; Li.sstk = 0; Li.la = 0;
       Li.cur = act ? tab[i] : 0u;
       Li.end = 0xFFFFFFFFu;
       SCtx<S> ci = c;

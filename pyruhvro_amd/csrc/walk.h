@@ -340,6 +340,7 @@ struct Lane {
   int64_t edetail;
   bool live, pres;     // an errored lane is dead: live = pres = false and its saved bits are cleared
   bool redo;           // fast walk only: this record left the fast wire forms and must be walked carefully
+  uint64_t la;         // look-ahead: the window bytes at `cur`, left behind by the head in front (read_head LA bit 1)
   uint32_t pstk;       // saved `pres` bits   (nullable record / union / list)
   uint32_t lstk;       // saved `live` bits   (list)
   uint64_t sstk;       // saved union selectors, 8 bits each
@@ -479,12 +480,24 @@ __device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nul
 // Head of a field for the lanes with `dec`: an optional single-byte null-union branch and an optional
 // varint (`wide`: may need more than 28 bits).  Returns isval (false for lanes without `dec`); v is the
 // varint when isval && want_varint.  L.cur moves past what was read.
-template <bool CAREFUL, bool TRUST = false, class Src>
+// Head fusion (LA, set per op by the generator -- specialize.cpp `la`): heads that are STATICALLY adjacent in the datum -- a
+// nullable record's branch byte and its first field's head, a boolean and the union index behind it, a union index and
+// the head of whichever variant it selects -- are decoded out of ONE window read.  Bit 1: this head leaves the bytes
+// behind what it consumed in L.la (every lane reads at its own cursor and shifts by what IT consumed, so L.la is valid
+// for every lane, decoding or not); (LA >> 2) = bytes the first head of a chain reads (4 / 8).  Bit 0: this head takes
+// its bytes from L.la and issues no read.  Chains never cross a string body, a loop boundary or 8 bytes, and exist only
+// in the fast walks (a careful walk may re-read a head byte by byte and would leave L.la stale).
+template <bool CAREFUL, bool TRUST = false, int LA = 0, class Src>
 __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
                                          bool wide, int64_t& v, bool small = false) {
   if (!nullable && !want_varint) return dec;
+  static_assert(LA == 0 || !CAREFUL, "head fusion is for the fast walks");
   const bool narrow = kNarrow && small && !wide;      // `small`: a length / index / count (see varint16)
-  const uint64_t x = (want_varint && wide) ? src.ld8(L.cur) : (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
+  uint64_t x;
+  if constexpr ((LA & 1) != 0) x = L.la;
+  else if constexpr ((LA & 2) != 0 && (LA >> 2) == 8) x = src.ld8(L.cur);
+  else if constexpr ((LA & 2) != 0) x = (uint64_t)src.ld4(L.cur);
+  else x = (want_varint && wide) ? src.ld8(L.cur) : (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
   // The fast size walk (neither careful nor trusted) checks a record's bounds ONCE, at its end (spec_size: cursor past
   // the record's end -> the wave is walked again, carefully): a cursor only ever moves forward, so a read that runs past
   // the end leaves it past the end for good, and what such a lane decodes meanwhile is never used.  No compare against
@@ -523,6 +536,7 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   }
   const bool slow = dec && (!okb || (isval && !okv));
   uint32_t adv = skip + ((isval && want_varint) ? n : 0u);
+  if constexpr ((LA & 2) != 0) L.la = x >> (8u * (dec ? adv : 0u));
   if (TRUST) {               // the size pass saw okb && okv on every lane of this tile: `slow` is dead
     L.cur += dec ? adv : 0u;
     return isval;
@@ -605,14 +619,14 @@ __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool ac
 // field handlers
 // --------------------------------------------------------------------------
 // int/long/float/double/boolean/date/timestamp leaf, optionally Nullable* (424-432, 434-473)
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   const bool dec = act && L.pres;
   const bool is_int = op.a == FK_I32 || op.a == FK_I64;
   int64_t v = 0;
   void* const pf1 = (EMIT && op.a != FK_BOOL) ? c.buf(op.buf1) : nullptr;     // requested ahead of the head: see h_string
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, is_int,
                                         op.a == FK_I64, v);
   uint64_t bits;
   bool valid;
@@ -620,7 +634,13 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     valid = isval && L.live;
     bits = op.a == FK_I32 ? (uint64_t)(uint32_t)(int32_t)v : (uint64_t)v;   // `as i32` truncates (424,430)
   } else {
-    const uint64_t x = op.a == FK_F64 ? src.ld8(L.cur) : op.a == FK_F32 ? src.ld5(L.cur) : (uint64_t)src.ld1(L.cur);
+    // (head fusion, read_head: a head-less leaf -- boolean / float without a null union -- may open or continue a chain)
+    constexpr int la = CAREFUL ? 0 : LA;
+    uint64_t x;
+    if constexpr ((la & 1) != 0) x = L.la;
+    else if constexpr ((la & 2) != 0 && (la >> 2) == 8) x = src.ld8(L.cur);
+    else if constexpr ((la & 2) != 0) x = (uint64_t)src.ld4(L.cur);
+    else x = op.a == FK_F64 ? src.ld8(L.cur) : op.a == FK_F32 ? src.ld5(L.cur) : (uint64_t)src.ld1(L.cur);
     const uint32_t avail = L.end - L.cur;
     const uint32_t need = op.a == FK_F32 ? 4u : op.a == FK_F64 ? 8u : 1u;
     const bool want = isval && L.live;
@@ -631,6 +651,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     RH_REJECT_SOFT(L, badb, E_BOOL, (int64_t)bits);
     valid = want && L.live;
     L.cur += valid ? need : 0u;
+    if constexpr ((la & 2) != 0) L.la = x >> (8u * (valid ? need : 0u));
   }
   if (!valid) bits = 0;   // zero under nulls (arrow-rs append_null)
   uint32_t row = 0;
@@ -652,7 +673,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
 }
 
 // string leaf / map key (429, 454-457, 752, read_string 902-922) and enum -> symbol text (570-578)
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   const bool dec = act && L.pres;
@@ -661,7 +682,7 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   // latency runs beside the LDS read instead of in front of each store (k_emit -1.2 %, profiles/r03at_variants_ab.txt)
   void* const pb1 = EMIT ? c.buf(op.buf1) : nullptr;
   void* const pb2 = EMIT ? c.buf(op.buf2) : nullptr;
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, true);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, true);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   bool sym_imm = false;
@@ -744,14 +765,14 @@ __device__ __forceinline__ void fill_zero(void* base, uint64_t off, uint32_t n) 
   for (; j < n; j++) st_at<uint8_t, WIDE>(base, off + j, (uint8_t)0);
 }
 
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   const bool dec = act && L.pres;
   const bool has_len = op.a == BN_DEC_BYTES || op.a == BN_UUID_STR;
   const uint32_t W = (uint32_t)op.c;
   int64_t v = 0;
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, has_len, false, v, true);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, has_len, false, v, true);
   const bool want = isval && L.live;
   uint32_t len = (uint32_t)op.b;
   if (has_len) {
@@ -839,13 +860,13 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
 }
 
 // NullableRecord (482-485 + 595-616): a null record null-fills its children
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.pres = valid;
@@ -856,7 +877,7 @@ __device__ __forceinline__ void h_rec_end(Lane& L) {
 }
 
 // UnionDecoder::decode / append_null (643-668): selected variant decodes, every other one null-fills
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
@@ -864,7 +885,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   const bool dec = act && L.pres;
   int64_t idx = 0;
   void* const pu1 = EMIT ? c.buf(op.buf1) : nullptr;           // requested ahead of the head: see h_string
-  const bool got = read_head<CAREFUL, RH_TRUST>(src, L, dec, false, false, true, false, idx, true) && L.live;
+  const bool got = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, false, false, true, false, idx, true) && L.live;
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
@@ -881,14 +902,14 @@ __device__ __forceinline__ void h_union_end(Lane& L) {
 }
 
 // ListDecoder / MapDecoder (+ Nullable*), 487-496, 703-770
-template <bool EMIT, bool CAREFUL, class Src, class Ctx>
+template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
   L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
   L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
-  const bool isval = read_head<CAREFUL, RH_TRUST>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
   put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.live = valid;      // only rows that really carry a list enter the block loop
