@@ -495,6 +495,27 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
         return (time.perf_counter() - t) * 1e3 / reps
     step.sync_call_ms = sync_call_ms
 
+    def other_form_ms(single_pass, reps=10):
+        """The same call on the OTHER form of the launch sequence -- RH_SINGLE_PASS (one kernel sizes, scans across tiles and
+        emits) when the timed steps were two-pass, RH_TWO_PASS when RUHVRO_HIP_SINGLE_PASS=1 made them single-pass -- every call
+        carrying the kernels' timestamps, in the same process on the same buffers."""
+        c = cabi.PreparedDeviceDecode(d_data.data_ptr(), d_off.data_ptr(), data_len, n, schema, num_chunks, device=local_rank,
+                                      stream=stream, kernel=KERNEL, chunk_rows=shard["chunk_rows"], two_pass=not single_pass,
+                                      single_pass=single_pass)
+        for _ in range(3):
+            c.free(c.run(False))
+        acc = {"size_kernel_ms": 0.0, "scan_kernel_ms": 0.0, "emit_kernel_ms": 0.0}
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            c.free(c.run(True))
+            for key in acc:
+                acc[key] += getattr(c.stats, key)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t) * 1e3 / reps
+        return wall, {key: v / reps for key, v in acc.items()}
+    step.other_form_ms = other_form_ms
+
     def parity_batches():
         """One more call of the TIMED configuration (rh_decode_device + RH_ASYNC on the timed stream, the shard's chunk
         geometry), settled and copied to the host: what `parity_check` compares with the oracle."""
@@ -756,14 +777,17 @@ def main(argv=None):
                 "emit_alg_GBps": (r["input_bytes"] + 8 * r["records"] + r["output_bytes"]) / (r["emit_kernel_ms"] * 1e-3) / 1e9
                 if r["emit_kernel_ms"] > 0 else 0.0} for i, r in enumerate(per_rank)]
     spec = bool(getattr(run, "info", {}).get("specialized"))
-    emit_kernel = "rh_spec_emit" if spec else "rh_k_emit"
+    # the single-pass form (one kernel sizes, scans across tiles and emits): no size / scan launches in the timed steps
+    single = spec and rs["size_kernel_ms"] == 0.0 and rs["emit_kernel_ms"] > 0 and gen_cfg != "flat4"
+    emit_kernel = "rh_spec_fused" if single else "rh_spec_emit" if spec else "rh_k_emit"
     size_kernel = "rh_spec_size" if spec else "rh_k_size"
     shard_whole = args.workload == "full10m" and not args.records
     # HBM bytes per launch from the stamped PMC passes: only for the launch they were measured on (1 GPU, 10M records)
     traffic = stamped_traffic(SCHEMAS[gen_cfg]) if world == 1 and shard_whole else {}
     size_ms, scan_ms = r0["size_kernel_ms"], r0["scan_kernel_ms"]
     kernels = {}
-    for name, ms, alg in ((size_kernel, size_ms, b_in + 8 * rs["records"]), ("rh_k_scan", scan_ms, 0), (emit_kernel, emit_ms, alg_bytes)):
+    for name, ms, alg in (((emit_kernel, emit_ms, alg_bytes),) if single else
+                          ((size_kernel, size_ms, b_in + 8 * rs["records"]), ("rh_k_scan", scan_ms, 0), (emit_kernel, emit_ms, alg_bytes))):
         t = traffic.get(name)
         k = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": int(alg),
              "alg_GBps": alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0}
@@ -773,7 +797,9 @@ def main(argv=None):
                       "hbm_GBps": t["hbm_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0})
         kernels[name] = k
     both_ms = size_ms + emit_ms
-    read_bytes = sum(traffic[k]["hbm_read_bytes"] for k in (size_kernel, emit_kernel)) if size_kernel in traffic and emit_kernel in traffic else None
+    path_kernels = (emit_kernel,) if single else (size_kernel, emit_kernel)
+    read_bytes = sum(traffic[k]["hbm_read_bytes"] for k in path_kernels) if all(k in traffic for k in path_kernels) else None
+    all_bytes = sum(traffic[k]["hbm_bytes"] for k in path_kernels) if all(k in traffic for k in path_kernels) else None
     roofline = {"bound": "hbm", "kernel": emit_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic[emit_kernel]["hbm_bytes"] if emit_kernel in traffic else None,
@@ -786,7 +812,15 @@ def main(argv=None):
                 "path_frac": alg_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if path_ms > 0 else 0.0,
                 "read_GBps": read_bytes / (both_ms * 1e-3) / 1e9 if read_bytes and both_ms > 0 else None,
                 "read_frac": read_bytes / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if read_bytes and both_ms > 0 else None,
-                "path_traffic": sum(t["hbm_bytes"] for n_, t in traffic.items() if n_.startswith("rh_")) if traffic else None,
+                # every HBM byte the path's kernels move (PMC, read + write) / their time: the single-pass form reads each
+                # record ONCE, so its READ rate is low by construction -- this is the figure that says how busy HBM is
+                "hbm_GBps": all_bytes / (both_ms * 1e-3) / 1e9 if all_bytes and both_ms > 0 else None,
+                "hbm_frac": all_bytes / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if all_bytes and both_ms > 0 else None,
+                "form": ("single pass: rh_spec_fused sizes a tile, scans across the tiles of its chunk (look-back) and emits out of the same LDS window; "
+                         "`frac` is the whole path's" if single else "two passes: size pass, scan + layout, emit pass; `frac` is the emit pass's"),
+                "path_traffic": (sum(traffic[n_]["hbm_bytes"] for n_ in (path_kernels + (("rh_k_layout", "rh_k_publish") if single else
+                                                                                      ("rh_k_scan_layout", "rh_k_publish"))) if n_ in traffic)
+                                 if all(k in traffic for k in path_kernels) else None),
                 "kernels": kernels}
     out = {
         "metric": "Avro records/sec -> Arrow (direct decode, input and output resident in HBM)",
@@ -809,8 +843,10 @@ def main(argv=None):
                    "parallelism": (f"{world} GPUs x whole reference chunks of ONE list (rh_shard_chunks), no data-path collective" if strong
                                    else f"{world} x independent 10M-record shard (weak), no data-path collective"),
                    "per_gpu": per_gpu,
-                   "kernel_ms": {"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
-                   "kernel_form": "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter",
+                   "kernel_ms": dict({"k_size": r0["size_kernel_ms"], "k_scan": r0["scan_kernel_ms"], "k_emit": r0["emit_kernel_ms"]},
+                                     **({"k_fused": r0["emit_kernel_ms"]} if single else {})),
+                   "kernel_form": ("schema-specialised, single pass (rh_spec_fused; `k_emit` is that kernel)" if single else
+                                   "schema-specialised" if getattr(run, "info", {}).get("specialized") else "generic interpreter"),
                    "emit_lds_bytes_per_workgroup": getattr(run, "info", {}).get("lds_bytes", 0),
                    "calls": ("synchronous: every step waits for its own call" if SYNC_CALLS else
                              f"RH_ASYNC on {STREAMS} stream(s), settled {PIPELINE_DEPTH} steps later (rh_device_result_wait), everything inside the timed region"),
@@ -819,6 +855,25 @@ def main(argv=None):
                    "path_alg_GBps": alg_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0},
         "roofline": roofline,
     }
+    if spec and world == 1 and shard_whole and hasattr(run.step, "other_form_ms"):
+        wall2, k2 = run.step.other_form_ms(single_pass=not single)
+        p2 = k2["size_kernel_ms"] + k2["scan_kernel_ms"] + k2["emit_kernel_ms"]
+        if single:
+            out["two_pass"] = {
+                "what": "the same call forced onto the two-pass form (RH_TWO_PASS), 10 synchronous calls with kernel timestamps, same process and buffers",
+                "sync_call_ms": wall2, "kernel_ms": {"k_size": k2["size_kernel_ms"], "k_scan": k2["scan_kernel_ms"], "k_emit": k2["emit_kernel_ms"]},
+                "emit_frac": alg_bytes / (k2["emit_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if k2["emit_kernel_ms"] > 0 else None,
+                "path_frac": alg_bytes / (p2 * 1e-3) / 1e9 / HBM_PEAK_GBPS if p2 > 0 else None}
+        elif k2["size_kernel_ms"] == 0.0 and k2["emit_kernel_ms"] > 0:
+            tf = traffic.get("rh_spec_fused")
+            out["single_pass"] = {
+                "what": ("the same call on the opt-in single-pass form (RH_SINGLE_PASS: rh_spec_fused sizes a tile, scans across the tiles of its "
+                         "chunk by look-back and emits out of the same LDS window -- every record read from HBM once), 10 synchronous calls with "
+                         "kernel timestamps, same process and buffers"),
+                "sync_call_ms": wall2, "kernel_ms": {"k_fused": k2["emit_kernel_ms"]},
+                "path_frac": alg_bytes / (k2["emit_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": tf["hbm_bytes"] if tf else None, "traffic_vs_algorithmic": tf["hbm_bytes"] / alg_bytes if tf else None,
+                "hbm_frac": tf["hbm_bytes"] / (k2["emit_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if tf else None}
     if getattr(run, "dist", None):
         out["dist"] = run.dist
     if getattr(run, "overlapped", None):

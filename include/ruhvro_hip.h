@@ -118,6 +118,19 @@ typedef struct {
  * pipeline of small batches keeps the GPU busy: a 1M-record call is 0.15 ms of kernels, and a synchronous call adds
  * ~25 us of host turn-around during which the GPU idles. */
 #define RH_ASYNC 8
+/* rh_decode_device only (ABI version 5), OR-ed into rh_opts.flags: the form of the launch sequence.
+ * Default = two passes: a size pass (per-record sizes, tile totals), a scan + arena layout, an emit pass; every record is read
+ * from HBM twice and 24 bytes of counters per record travel between the passes (4.8 GB per 10M benchmark records).
+ * RH_SINGLE_PASS: prefer the single-pass form -- ONE kernel that sizes a tile, scans across the tiles of its chunk
+ * (decoupled look-back, fence-free) and emits out of the same LDS window, into an arena laid out from per-column capacities
+ * (the schema's size history): 3.0 GB per 10M records, 1.02 x the algorithmic bytes.  Needs the schema-specialised kernels
+ * and a size history (a schema's first call is two-pass); a call that outgrows a capacity is repeated on the two-pass form
+ * and the schema backs off.  Same buffers either way.  Measured on MI355X (profiles/r04v_*): about time-neutral at 10M
+ * records (0.96-1.00 ms against 0.99-1.01), slower on small launches (the look-back wait is a fixed cost per tile) -- which
+ * is why it is opt-in: its use is a deployment that is short of HBM bandwidth, not of time.  RUHVRO_HIP_SINGLE_PASS=1 makes it
+ * the preference of every call; RH_TWO_PASS forces the two-pass form regardless. */
+#define RH_TWO_PASS 16
+#define RH_SINGLE_PASS 32
 
 struct rh_stats {
   uint64_t records;
@@ -227,7 +240,9 @@ enum {
   RH_CTR_WIDE_FALLBACKS = 3,   /* NeedWideIndex: a call re-run on the generic kernels (64-bit in-buffer offsets)    */
   RH_CTR_OFFSET32_ERRORS = 4,  /* calls refused because a chunk's column exceeds 32-bit Arrow offsets               */
   RH_CTR_SPLIT_CALLS = 5,      /* device-resident calls that dealt their chunk groups to internal streams (in-call overlap) */
-  RH_CTR_COUNT = 6
+  RH_CTR_SINGLE_PASS_CALLS = 6, /* decode calls that took the single-pass form (one kernel sizes, scans across tiles and emits) */
+  RH_CTR_SINGLE_PASS_FAILOVERS = 7, /* ... of which outgrew a column capacity and were repeated on the two-pass form */
+  RH_CTR_COUNT = 8
 };
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 

@@ -137,7 +137,7 @@ def lib():
     return _lib
 
 
-ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls")
+ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers")
 
 
 def engine_counters() -> dict:
@@ -193,6 +193,8 @@ def _import_chunks(arr, k: int, schema: pa.Schema) -> List[pa.RecordBatch]:
 
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALIZED = 0, 1, 2
+RH_TWO_PASS = 16  # rh_opts.flags: rh_decode_device takes the two-pass form (size pass, scan, emit pass) even where the single-pass form would run
+RH_SINGLE_PASS = 32  # rh_opts.flags: rh_decode_device prefers the single-pass form (one kernel sizes, scans across tiles, emits)
 RH_ASYNC = 8      # rh_opts.flags: rh_decode_device returns once the call is on the stream (rh_device_result_wait settles it)
 
 
@@ -427,7 +429,7 @@ def encode_device(batch_array_addr: int, batch_schema_addr: int, schema_json: st
 
 def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
                   device: int = -1, stream: int = 0, want_stats: bool = True, kernel: int = KERNEL_AUTO,
-                  chunk_rows: int = 0, asynchronous: bool = False) -> DeviceResult:
+                  chunk_rows: int = 0, asynchronous: bool = False, two_pass: bool = False, single_pass: bool = False) -> DeviceResult:
     """rh_decode_device on raw device pointers (e.g. torch tensors' data_ptr()).  chunk_rows: explicit geometry
     for a range of a larger call's chunks (rh_opts.chunk_rows).  asynchronous: RH_ASYNC -- the result is returned
     unsettled (DeviceResult.wait() settles it and fills .stats; every accessor settles implicitly)."""
@@ -436,7 +438,8 @@ def decode_device(d_data: int, d_offsets: int, data_len: int, n: int, schema_jso
     out = C.c_void_p()
     st = RhStats()
     err = C.c_char_p()
-    opts, _keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0), stream, None, chunk_rows)
+    opts, _keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0) | (RH_TWO_PASS if two_pass else 0) |
+                            (RH_SINGLE_PASS if single_pass else 0), stream, None, chunk_rows)
     rc = L.rh_decode_device(s.handle, d_data, d_offsets, data_len, n, num_chunks, C.byref(opts), C.byref(out),
                             C.byref(st) if want_stats else None, C.byref(err))
     if rc != RH_OK:
@@ -453,10 +456,12 @@ class PreparedDeviceDecode:
     every run(want_stats=True)."""
 
     def __init__(self, d_data: int, d_offsets: int, data_len: int, n: int, schema_json: str, num_chunks: int,
-                 device: int = -1, stream: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0, asynchronous: bool = False):
+                 device: int = -1, stream: int = 0, kernel: int = KERNEL_AUTO, chunk_rows: int = 0, asynchronous: bool = False,
+                 two_pass: bool = False, single_pass: bool = False):
         self._L = lib()
         self._schema = Schema.get(schema_json)
-        self._opts, self._keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0), stream, None, chunk_rows)
+        self._opts, self._keep = make_opts(device, kernel | (RH_ASYNC if asynchronous else 0) | (RH_TWO_PASS if two_pass else 0) |
+                                           (RH_SINGLE_PASS if single_pass else 0), stream, None, chunk_rows)
         self._wait = self._L.rh_device_result_wait
         self.stats = RhStats()
         self._out = C.c_void_p()

@@ -214,10 +214,12 @@ extern "C" uint32_t rh_enc_lds_bytes(int ndom, int list_depth) {
   return rh::enc_lds_fixed_bytes((uint32_t)((ndom > 0 ? ndom : 1) + (list_depth > 0 ? list_depth : 1)) * rh::kBlock);
 }
 extern "C" int rh_launch_esize(const rh::EParams* P, uint32_t lds_bytes, void* stream) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_e_size, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_eemit(const rh::EParams* P, uint32_t lds_bytes, void* stream) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_e_emit, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, *P);
   return (int)hipGetLastError();
 }

@@ -73,6 +73,7 @@ struct ValueClassError : std::runtime_error {   // data-dependent failures of ot
   using std::runtime_error::runtime_error;
 };
 struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic kernels index that far
+struct NeedTwoPass {};     // the single-pass form outgrew a column capacity (or needs what only the two-pass layout checks): repeat
 
 std::atomic<uint64_t> g_counters[RH_CTR_COUNT];     // rh_engine_counters (include/ruhvro_hip.h)
 inline void count(int which) { g_counters[which].fetch_add(1, std::memory_order_relaxed); }
@@ -278,6 +279,7 @@ struct DeviceProgram {
 struct SpecKernel {      // schema-specialised k_size / k_emit loaded on one device
   hipModule_t mod = nullptr;
   hipFunction_t size_fn = nullptr, emit_fn = nullptr;
+  hipFunction_t fused_fn = nullptr;      // the single-pass form (decode kernels only)
   bool ok = false;
   std::string why;
 };
@@ -294,6 +296,12 @@ struct rh_schema {
   // the next call BEFORE its totals are known, so that the call is one stream submission (decode_device_impl1).
   // 0 = no history yet (the first call of a schema lays its arena out on the host, after the scan).
   std::atomic<double> arena_ratio{0.0};
+  // Single-pass form: what every counter's column needed PER ROW of a chunk in the last settled call (the largest chunk's
+  // figure): sizes each column's capacity before the launch (rh_decode_call::try_single).  Empty = no history.  A call that
+  // outgrows its capacities is repeated on the two-pass form and the schema sits the next calls out (backing off: data that
+  // keeps changing character stays on the two-pass form, one outlier batch costs eight calls).
+  std::vector<double> per_row;
+  uint32_t single_cooldown = 0, single_backoff = 0;      // calls the single pass sits out after a fail-over (8, 16, ... 1024; a success clears it)
 };
 
 namespace {
@@ -350,6 +358,9 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile, bool
       if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.size_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.emit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (!encode && hipModuleGetFunction(&k.fused_fn, k.mod, "rh_spec_fused") == hipSuccess)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.fused_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      else k.fused_fn = nullptr;
       (void)hipGetLastError();
       k.ok = true;
     }
@@ -493,6 +504,7 @@ struct rh_device_result {
   std::vector<uint64_t> buf_size;      // [nbuf][k] allocated bytes
   std::vector<uint64_t> dom_rows;      // [ndom][k]
   std::vector<uint64_t> data_bytes;    // [K][k] totals
+  std::vector<uint64_t> layout_bytes;  // [K][k] single-pass form: the CAPACITIES the arena was laid out with (empty: laid out exactly)
   std::vector<uint32_t> nullcount;     // [nnodes][k]
   uint64_t output_bytes = 0;           // exact (unpadded) Arrow bytes
   // The [buf][chunk] tables above are a pure function of (schema, chunk geometry, data_bytes).  A call whose arena was
@@ -529,15 +541,21 @@ void rh_device_result::fill_tables() {
   buf_off.assign((size_t)nbuf * k, 0);
   buf_size.assign((size_t)nbuf * k, 0);
   uint64_t off = 0, exact = 0;
+  const bool capl = !layout_bytes.empty();      // slots as the single-pass form reserved them; sizes are the real ones
   for (uint32_t c = 0; c < k; c++) {
     for (int b = 0; b < nbuf; b++) {
       const rh::BufDesc& d = c_s.bufs[b];
       uint64_t ex = 0;
       const uint64_t bytes = rh::buf_bytes(d.kind, rows(d.dom, c), d.kind == rh::BK_DATA ? data_bytes[(size_t)d.counter * k + c] : 0, &ex,
                                            (uint32_t)d.counter);
+      uint64_t slot = bytes;
+      if (capl) {
+        const uint64_t crow = d.dom == 0 ? rows(0, c) : layout_bytes[(size_t)(d.dom - 1) * k + c];
+        slot = rh::buf_bytes(d.kind, crow, d.kind == rh::BK_DATA ? layout_bytes[(size_t)d.counter * k + c] : 0, nullptr, (uint32_t)d.counter);
+      }
       buf_off[(size_t)b * k + c] = off;
       buf_size[(size_t)b * k + c] = bytes;
-      off += rh::buf_slot_bytes(bytes);
+      off += rh::buf_slot_bytes(slot);
       exact += ex;
     }
   }
@@ -732,6 +750,8 @@ void export_field(const rh::ArrowField& f, ArrowSchema* out) {
 // the launch sequence
 // ---------------------------------------------------------------------------
 // integer knob from the environment, read at every use (tests change them inside one process); out of range = default
+constexpr long kSinglePassDefault = 0;           // RUHVRO_HIP_SINGLE_PASS: 1 = every qualifying call prefers the single-pass form (else RH_SINGLE_PASS per call)
+constexpr int RH_INTERNAL_TWO_PASS = 0x100;      // rh_opts.flags, engine-internal: this call must take the two-pass path
 constexpr long kInternalStreamsDefault = 1;      // RUHVRO_HIP_INTERNAL_STREAMS (decode_device_split)
 constexpr long kSplitMinDefault = 1000000;       // RUHVRO_HIP_SPLIT_MIN: records below which a call is never split
 
@@ -774,7 +794,11 @@ struct Events {
   }
   void rec(int i, hipStream_t s) { if (on) HIPCHK(hipEventRecord(e[i], s)); }
   hipEvent_t at(int i) const { return on ? e[i] : nullptr; }
-  float ms(int a, int b) { float t = 0; if (on) (void)hipEventElapsedTime(&t, e[a], e[b]); return t; }
+  float ms(int a, int b) {
+    float t = 0;
+    if (on && hipEventElapsedTime(&t, e[a], e[b]) != hipSuccess) { t = 0; (void)hipGetLastError(); }   // (a pair that was never recorded: no sticky error left behind)
+    return t;
+  }
 };
 
 // "This call's work is done" markers of asynchronous calls (RH_ASYNC): hipStreamSynchronize would also wait for every
@@ -822,6 +846,7 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
                                      uint64_t n, uint64_t num_chunks, const rh_opts* opts, rh_stats* stats,
                                      const ChunkGeo* geo = nullptr) {
   try {
+  try {
     // in-call overlap (decode_device_split): a large call deals its chunk groups to internal streams
     const long G = env_long("RUHVRO_HIP_INTERNAL_STREAMS", kInternalStreamsDefault, 1, 8);
     const long groups_env = env_long("RUHVRO_HIP_SPLIT_GROUPS", 0, 0, 64);      // (> 1 with one stream: the groups run back to back)
@@ -851,6 +876,12 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
       }
     }
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, opts, stats, geo);
+  } catch (const NeedTwoPass&) {
+    rh_opts o = default_opts();
+    if (opts) o = *opts;
+    o.flags |= RH_INTERNAL_TWO_PASS;
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats, geo);
+  }
   } catch (const NeedWideIndex&) {
     count(RH_CTR_WIDE_FALLBACKS);
     rh_opts o = default_opts();
@@ -904,6 +935,11 @@ struct rh_decode_call {
   uint64_t* d_sizes = nullptr;
   uint64_t exact = 0;
   bool child_bitmaps = false, fused = false, timed_size = false;
+  bool range_of_host_call = false;   // a chunk range of a host call (decode_range) or a group of a split call: the caller gave the geometry
+  bool single = false;          // the single-pass form ran (rh_spec_fused): arena laid out from capacities
+  std::vector<uint64_t> caps;   // [K][k] those capacities
+  uint64_t arena_cap = 0, o_tick = 0;
+  Lease lookback, hcaps;
   double basis = 0;
   bool settled = false;         // finish() ran (or the call completed inside enqueue())
   bool async = false;           // RH_ASYNC: the call is settled later; without rh_k_publish its end is marked with a DoneEvent
@@ -920,7 +956,7 @@ struct rh_decode_call {
       : s(s_), cs(*s_->cs), d_data(data), d_offsets(offs), data_len(dl), n(n_), num_chunks(nc), opts(o ? *o : default_opts()),
         want_stats(stats), r(res) {
     std::memset(&st, 0, sizeof st);
-    if (g) { geo_v = *g; geo = &geo_v; }
+    if (g) { geo_v = *g; geo = &geo_v; range_of_host_call = true; }
     opts.devices = nullptr; opts.n_devices = 0; opts.device_stats = nullptr; opts.ready = nullptr; opts.gathered = nullptr;   // (not used below; never dangling)
   }
 
@@ -988,6 +1024,95 @@ struct rh_decode_call {
     check_bad(hctrl.ptr());
   }
 
+  // The single-pass form (spec_body.h spec_fused): k_layout over per-column CAPACITIES from the schema's history, then ONE
+  // kernel that sizes, scans across tiles (look-back) and emits, then rh_k_publish.  Returns false when the call does not
+  // qualify (no history yet, generic kernels, knobs) -- the two-pass submission follows then.
+  bool try_single(bool two_sync, long ratio_hook) {
+    const bool on = (opts.flags & RH_SINGLE_PASS) != 0 || env_long("RUHVRO_HIP_SINGLE_PASS", kSinglePassDefault, 0, 1) != 0;
+    // (device-resident calls only: a host call is bound by the PCIe link, and its D2H copy would carry the capacity slack)
+    if (!on || range_of_host_call || (opts.flags & (RH_INTERNAL_TWO_PASS | RH_TWO_PASS)) || !sk || !sk->fused_fn || K <= 0 || K > 64 || n == 0 || two_sync ||
+        ratio_hook >= 0)
+      return false;
+    if (n_entries > (1u << 16)) return false;
+    std::vector<double> per_row;
+    {
+      std::lock_guard<std::mutex> g(s->mu);
+      if ((int)s->per_row.size() != K) return false;
+      if (s->single_cooldown > 0) { s->single_cooldown--; return false; }
+      per_row = s->per_row;
+    }
+    // capacities: what the last call needed per row, + 4 % + a pad that covers a short chunk's noise; never more than the
+    // 32-bit limits the kernels index with (a column that needs more overflows its capacity -> two-pass -> the usual errors)
+    // (RUHVRO_HIP_SINGLE_SLACK_PERMILLE: knob / test hook -- below 1000 the capacities are smaller than what the last call
+    //  needed, which forces the LF_CAPACITY fail-over to the two-pass form)
+    const double slack = (double)env_long("RUHVRO_HIP_SINGLE_SLACK_PERMILLE", 1040, 1, 4000) / 1000.0;
+    caps.assign((size_t)K * k, 0);
+    for (int kk = 0; kk < K; kk++)
+      for (uint32_t c = 0; c < k; c++) {
+        const uint64_t rows_c = c == k - 1 ? r.rows_last : r.sz;
+        uint64_t cap = (uint64_t)(per_row[(size_t)kk] * (double)rows_c * slack) + (slack >= 1.0 ? 4096 : 0);
+        uint64_t lim = 0x7FFFFFFFull;
+        if (kk < cs.ndom - 1) lim = std::min<uint64_t>(lim, narrow_rows - 1);       // a child row domain
+        caps[(size_t)kk * k + c] = std::min(cap, lim);
+      }
+    {   // arena bytes of that layout (the rule of fill_tables / rh_k_layout)
+      uint64_t off = 0;
+      for (uint32_t c = 0; c < k; c++)
+        for (int b = 0; b < nbuf; b++) {
+          const rh::BufDesc& d = cs.bufs[b];
+          const uint64_t rows0 = c == k - 1 ? r.rows_last : r.sz;
+          const uint64_t rows = d.dom == 0 ? rows0 : caps[(size_t)(d.dom - 1) * k + c];
+          off += rh::buf_slot_bytes(rh::buf_bytes(d.kind, rows, d.kind == rh::BK_DATA ? caps[(size_t)d.counter * k + c] : 0, nullptr, (uint32_t)d.counter));
+        }
+      arena_cap = std::max<uint64_t>(off, kAlign);
+    }
+    count(RH_CTR_SINGLE_PASS_CALLS);
+    count(RH_CTR_FUSED_CALLS);             // (a single stream submission too)
+    single = true; fused = true;
+    r.arena = Lease(dev_pool(), arena_cap, device);
+    lookback = Lease(dev_pool(), std::max<uint64_t>(8ull * K * nblocks, kAlign), device);
+    HIPCHK(hipMemsetAsync(lookback.ptr(), 0, 8ull * K * nblocks, stream));
+    // the capacities go to the device behind the leading words of the workspace's blocksum area (unused on this path)
+    hcaps = Lease(pin_pool(), 8ull * K * k, device);
+    std::memcpy(hcaps.ptr(), caps.data(), 8ull * K * k);
+    uint64_t* d_caps = (uint64_t*)P.blocksum;
+    if (8ull * K * k > 4ull * K * nblocks) { single = false; fused = false; r.arena.release(); lookback.release(); hcaps.release(); return false; }
+    HIPCHK(hipMemcpyAsync(d_caps, hcaps.ptr(), 8ull * K * k, hipMemcpyHostToDevice, stream));
+    P.lookback = (unsigned long long*)lookback.ptr();
+    P.caps = d_caps;
+    rh::LParams LP;
+    std::memset(&LP, 0, sizeof LP);
+    LP.totals = d_caps; LP.desc = dp->desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
+    LP.nbuf = nbuf; LP.K = K; LP.ndom = cs.ndom; LP.arena = r.arena.ptr(); LP.capacity = r.arena.b.size;
+    LP.bufptr = (void**)dtab.ptr(); LP.bufsize = d_sizes; LP.ctrl = P.first_bad; LP.narrow = 0;
+    LP.narrow_rows = narrow_rows;
+    if (rh_launch_layout(&LP, stream)) throw HipError("k_layout launch failed");
+    if (nbuf > 0 && child_bitmaps && rh_launch_init(P.bufptr, d_sizes, dp->desc, (uint32_t)nbuf, k, P.first_bad, stream))
+      throw HipError("k_init launch failed");
+    const uint64_t tiles_max = std::max<uint64_t>((r.sz + tile - 1) / tile, (r.rows_last + tile - 1) / tile);
+    emit_lds = lds_bytes;
+    if (launch_module(sk->fused_fn, P, (uint32_t)(tiles_max * k), (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4)))
+      throw HipError("k_fused launch failed");
+    basis = (double)payload + 64.0 * (double)n;
+    void* hdev = nullptr;
+    if (hipHostGetDevicePointer(&hdev, hctrl.ptr(), 0) == hipSuccess && hdev) {
+      static std::atomic<uint32_t> next_token{0x40000001u};
+      token = next_token.fetch_add(1);
+      if (token == 0) token = next_token.fetch_add(1);
+      o_flag_h = align_up(o_null + 4ull * nnodes * k, 8);
+      *(volatile uint32_t*)(hctrl.ptr() + o_flag_h) = 0;
+      if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, stream))
+        throw HipError("k_publish launch failed");
+      ctrl->b.clean = true;
+      published = true;
+    } else {
+      (void)hipGetLastError();
+      HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
+      if (async) done.record(device, stream);
+    }
+    return true;
+  }
+
   void enqueue() {
     Range rk("ruhvro_hip:decode_device (k_size, k_scan, k_layout, k_init, k_emit)");
     if (opts.device >= 0) { HIPCHK(hipSetDevice(opts.device)); device = opts.device; }
@@ -1048,7 +1173,8 @@ struct rh_decode_call {
     // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*null_slots]
     //      workspace: errinfo | blocksum | blockbase | tileflag | lanecnt
     o_tot = 32;      // control words first (program.h): first_bad, layout flag, arena bytes used
-    o_null = align_up(o_tot + 8ull * K * k, 16);
+    o_tick = o_tot + 8ull * K * k;                    // [k] tile tickets of the single-pass form (zero like the rest of the block)
+    o_null = align_up(o_tick + 4ull * k, 16);
     null_slots = rh::null_slots_for(k);
     ctrl_bytes = align_up(o_null + 4ull * nnodes * k * null_slots, kAlign);
     const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
@@ -1073,6 +1199,7 @@ struct rh_decode_call {
     P.nullcount = (uint32_t*)(ctrl->ptr() + o_null);
     P.null_slots = null_slots;
     P.totals = (uint64_t*)(ctrl->ptr() + o_tot);
+    P.tickets = (uint32_t*)(ctrl->ptr() + o_tick);
     P.errinfo = (rh::ErrInfo*)(ws.ptr() + o_err);
     P.blocksum = (uint32_t*)(ws.ptr() + o_bsum);
     P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
@@ -1137,8 +1264,9 @@ struct rh_decode_call {
     fused = n > 0 && ratio > 0 && !two_sync && n_entries <= (1u << 16);
     // stage timings (rh_stats) come from the kernels' own start / stop timestamps: e0..e1 = k_size, e5..e2 = k_scan,
     // e3..e4 = k_emit
-    timed_size = n > 0 && K > 0;
     if (start_after) HIPCHK(hipStreamWaitEvent(stream, start_after, 0));
+    if (try_single(two_sync, ratio_hook)) return;
+    timed_size = n > 0 && K > 0;
     if (timed_size) {
       if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
              : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
@@ -1226,7 +1354,24 @@ struct rh_decode_call {
       check_bad(hctrl.ptr());
       if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
       const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
-      if (lflag & rh::LF_CAPACITY) {
+      if (single) {
+        ctrl->b.clean = published;
+        if (lflag) {            // a column outgrew its capacity (or the capacity layout was refused): the two-pass path decides
+          // (not latched when the capacities were shrunk by the test hook)
+          if ((lflag & rh::LF_CAPACITY) && env_long("RUHVRO_HIP_SINGLE_SLACK_PERMILLE", 1040, 1, 4000) >= 1000) {
+            std::lock_guard<std::mutex> g(s->mu);
+            s->single_backoff = std::min<uint32_t>(1024, std::max<uint32_t>(8, s->single_backoff * 2));
+            s->single_cooldown = s->single_backoff;
+          }
+          count(RH_CTR_SINGLE_PASS_FAILOVERS);
+          r.arena.release();
+          throw NeedTwoPass();
+        }
+        r.data_bytes = totals;
+        r.layout_bytes = caps;
+        r.arena_bytes = arena_cap;
+        { std::lock_guard<std::mutex> g(s->mu); s->single_backoff = 0; }
+      } else if (lflag & rh::LF_CAPACITY) {
         count(RH_CTR_CAPACITY_RETRIES);
         r.arena.release();
         exact_tail();                              // (throws the offset-overflow / wide-index cases itself)
@@ -1250,9 +1395,19 @@ struct rh_decode_call {
       }
       exact_tail();
     }
-    if (n > 0 && basis > 0) {
+    if (n > 0 && basis > 0 && !single) {
       const double slots = (double)n_entries * (double)kAlign;
       s->arena_ratio.store(std::max(0.0, (double)r.arena_bytes - slots) / basis + 1e-9);
+    }
+    if (n > 0 && K > 0 && (int)totals.size() == K * (int)k) {       // per-row need of every counter's column (single-pass capacities)
+      std::vector<double> pr((size_t)K, 0.0);
+      for (int kk = 0; kk < K; kk++)
+        for (uint32_t c = 0; c < k; c++) {
+          const uint64_t rows_c = c == k - 1 ? r.rows_last : r.sz;
+          if (rows_c) pr[(size_t)kk] = std::max(pr[(size_t)kk], (double)totals[(size_t)kk * k + c] / (double)rows_c);
+        }
+      std::lock_guard<std::mutex> g(s->mu);
+      s->per_row = std::move(pr);
     }
     r.nullcount.assign((size_t)nnodes * k, 0);
     if (published) {           // rh_k_publish summed the slots: one word per (node, chunk)
@@ -1273,9 +1428,12 @@ struct rh_decode_call {
       for (int r0 = 0; r0 < 64; r0++)
         for (int i = 0; i < 32; i++) h[i] += hr[r0 * 32 + i];
       const double waves = (double)nblocks * 4;
-      static const char* names[] = {"offsets", "stage+barrier", "lane_init", "walk1", "scan", "barrier", "layout", "walk2",
-                                    "errors+barrier", "flush"};
-      std::fprintf(stderr, "[ruhvro_hip profile] emit cycles/wave:");
+      static const char* names2[] = {"offsets", "stage+barrier", "lane_init", "walk1", "scan", "barrier", "layout", "walk2",
+                                     "errors+barrier", "flush"};
+      static const char* names1[] = {"ticket+zero+barrier", "offsets+stage+barrier", "size_walk", "wave_scan", "barrier", "lookback(wave0)",
+                                     "barrier", "prefix", "emit_walk", "errors+flush"};
+      const char* const* names = single ? names1 : names2;
+      std::fprintf(stderr, "[ruhvro_hip profile] %s cycles/wave:", single ? "single-pass" : "emit");
       for (int i = 0; i < 10; i++) std::fprintf(stderr, " %s=%.0f", names[i], h[i] / waves);
       std::fprintf(stderr, "\n[ruhvro_hip profile] size cycles/wave: stage+barrier=%.0f init=%.0f walk=%.0f tail=%.0f | kernels ms: size=%.3f emit=%.3f\n",
                    h[16] / waves, h[17] / waves, h[18] / waves, h[19] / waves, ev.ms(0, 1), ev.ms(3, 4));
@@ -1286,14 +1444,14 @@ struct rh_decode_call {
       st.output_bytes = exact;
       st.chunks = k;
       st.blocks = nblocks;
-      st.size_kernel_ms = timed_size ? ev.ms(0, 1) : 0.f;
-      st.scan_kernel_ms = timed_size ? ev.ms(5, 2) : 0.f;
+      st.size_kernel_ms = (timed_size && !single) ? ev.ms(0, 1) : 0.f;
+      st.scan_kernel_ms = (timed_size && !single) ? ev.ms(5, 2) : 0.f;
       st.emit_kernel_ms = n > 0 ? ev.ms(3, 4) : 0.f;
       st.specialized = sk ? 1 : 0;
       st.lds_bytes = emit_lds;
     }
     // the call's scratch goes back to the pools now (the control block is zeroed on its stream, CtrlPool)
-    ws.release(); dtab.release(); hctrl.release(); prof_buf.release(); ctrl.reset();
+    ws.release(); dtab.release(); hctrl.release(); prof_buf.release(); lookback.release(); hcaps.release(); ctrl.reset();
   }
 
   // a call that failed (or is abandoned) must not hand its blocks back while the GPU may still be using them
@@ -1476,28 +1634,43 @@ void settle(rh_device_result* r) {
   }
   if (!r->pending) return;
   std::unique_ptr<DeviceDecode> call = std::move(r->pending);
+  // the call again, synchronously, on another form: the two-pass form (a single-pass call that outgrew a capacity) or the
+  // generic kernels (a child row domain beyond 32-bit indexing -- which the two-pass repeat may itself run into)
+  auto rerun = [&](int add_flags, bool generic) {
+    call->drain();
+    if (generic) count(RH_CTR_WIDE_FALLBACKS);
+    rh_opts o = call->opts;
+    o.flags = generic ? ((o.flags & ~(3 | RH_ASYNC)) | RH_KERNEL_GENERIC) : ((o.flags & ~RH_ASYNC) | add_flags);
+    rh_stats st2;
+    std::memset(&st2, 0, sizeof st2);
+    std::unique_ptr<rh_device_result> r2;
+    try {
+      r2.reset(decode_device_impl1(call->s, call->d_data, call->d_offsets, call->data_len, call->n, call->num_chunks, &o,
+                                   call->want_stats ? &st2 : nullptr, call->geo));
+    } catch (const NeedWideIndex&) {
+      if (generic) throw;
+      count(RH_CTR_WIDE_FALLBACKS);
+      o.flags = (o.flags & ~3) | RH_KERNEL_GENERIC;
+      r2.reset(decode_device_impl1(call->s, call->d_data, call->d_offsets, call->data_len, call->n, call->num_chunks, &o,
+                                   call->want_stats ? &st2 : nullptr, call->geo));
+    }
+    call.reset();                                  // (its reference to *r ends here)
+    r->arena = std::move(r2->arena);
+    r->arena_bytes = r2->arena_bytes;
+    r->buf_off = std::move(r2->buf_off); r->buf_size = std::move(r2->buf_size); r->dom_rows = std::move(r2->dom_rows);
+    r->data_bytes = std::move(r2->data_bytes); r->nullcount = std::move(r2->nullcount); r->layout_bytes = std::move(r2->layout_bytes);
+    r->output_bytes = r2->output_bytes; r->tables_done = r2->tables_done;
+    r->k = r2->k; r->sz = r2->sz; r->rows_last = r2->rows_last;
+    if (r2->has_stats || st2.records) { r->st = st2; r->has_stats = true; }
+  };
   try {
     try {
       call->finish();
       if (call->want_stats) { r->st = call->st; r->has_stats = true; }
+    } catch (const NeedTwoPass&) {
+      rerun(RH_INTERNAL_TWO_PASS, false);
     } catch (const NeedWideIndex&) {
-      call->drain();
-      count(RH_CTR_WIDE_FALLBACKS);
-      rh_opts o = call->opts;
-      o.flags = RH_KERNEL_GENERIC;
-      rh_stats st2;
-      std::memset(&st2, 0, sizeof st2);
-      std::unique_ptr<rh_device_result> r2(decode_device_impl1(call->s, call->d_data, call->d_offsets, call->data_len, call->n,
-                                                               call->num_chunks, &o, call->want_stats ? &st2 : nullptr,
-                                                               call->geo));
-      call.reset();                                  // (its reference to *r ends here)
-      r->arena = std::move(r2->arena);
-      r->arena_bytes = r2->arena_bytes;
-      r->buf_off = std::move(r2->buf_off); r->buf_size = std::move(r2->buf_size); r->dom_rows = std::move(r2->dom_rows);
-      r->data_bytes = std::move(r2->data_bytes); r->nullcount = std::move(r2->nullcount);
-      r->output_bytes = r2->output_bytes; r->tables_done = r2->tables_done;
-      r->k = r2->k; r->sz = r2->sz; r->rows_last = r2->rows_last;
-      if (r2->has_stats || st2.records) { r->st = st2; r->has_stats = true; }
+      rerun(0, true);
     }
   } catch (...) {
     if (call) call->drain();
@@ -1588,6 +1761,9 @@ int guarded(char** err, F&& f) {
     return RH_ERR_ARGUMENT;
   } catch (const std::exception& e) {
     if (err) *err = dup_msg(e.what());
+    return RH_ERR_RUNTIME;
+  } catch (...) {            // (an engine-internal signal that no handler claimed must never take the process down)
+    if (err) *err = dup_msg("internal error: unhandled engine signal");
     return RH_ERR_RUNTIME;
   }
 }

@@ -474,16 +474,19 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
 // launchers (called from engine.cpp; plain C linkage, HIP types stay in here)
 // --------------------------------------------------------------------------
 extern "C" int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipExtLaunchKernelGGL(rh::rh_k_size, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipExtLaunchKernelGGL(rh::rh_k_scan, dim3((uint32_t)P->K * P->k), dim3(rh::kBlock), 0, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_scan_layout(const rh::KParams* P, const rh::LParams* L, void* stream, void* start, void* stop) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipExtLaunchKernelGGL(rh::rh_k_scan_layout, dim3((uint32_t)P->K * P->k), dim3(rh::kBlock), 0, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P, *L);
   return (int)hipGetLastError();
@@ -491,21 +494,25 @@ extern "C" int rh_launch_scan_layout(const rh::KParams* P, const rh::LParams* L,
 
 extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf,
                               uint32_t k, const unsigned long long* ctrl, void* stream) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_k_init, dim3(nbuf * k), dim3(rh::kBlock), 0, (hipStream_t)stream, bufptr, bufsize, desc,
                      nbuf, k, ctrl);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token,
                                  uint32_t nslots, void* stream) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, head_words,
                      null_entries, flag_word, token, nslots);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_k_layout, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, *L);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
+  (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipExtLaunchKernelGGL(rh::rh_k_emit, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();

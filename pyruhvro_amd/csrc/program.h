@@ -202,6 +202,10 @@ struct KParams {
   uint32_t* lanecnt;         // [nblocks*TILE][ceil(K/2)] per-record counters, 16 bits each (saturated at 0xFFFF), record-major
   uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
+  // single-pass form (spec_body.h spec_fused): one launch sizes, scans (decoupled look-back over the tiles of a chunk) and emits
+  unsigned long long* lookback;   // [nblocks][K] tile state words: bits 63..62 = 1 tile total / 2 inclusive prefix, low 32 bits = value; zero = not there yet
+  const uint64_t* caps;      // [K][k] capacity of every counter's column per chunk (rows / bytes the arena reserves for it)
+  uint32_t* tickets;         // [k] next tile of every chunk (zero at launch): tiles are taken in the order workgroups START
   uint32_t null_slots;       // null_slots_for(k): a power of two <= kNullSlots
   uint32_t all_careful;      // 1: no size pass classified the tiles (schemas without variable-length output): the emit kernel walks every tile carefully
 };

@@ -161,10 +161,10 @@ __device__ __forceinline__ void lanecnt_load(const uint32_t* row, uint32_t (&d)[
   }
 }
 
-// LDS in front of the window: wtot[NW][KP] (KP = K rounded up to 4: a wavefront's totals are one contiguous, 16-byte aligned row) | nullcnt[NNODES] | nullw[NNODES][NW] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
+// LDS in front of the window: wtot[NW][KP] (KP = K rounded up to 4: a wavefront's totals are one contiguous, 16-byte aligned row) | gbx[KP + 128] | nullcnt[NNODES] | nullw[NNODES][NW] | misc[4] | bm[NBM][kBmWords] | dtab[NW][kDenseCap] (schemas with
 // a dense list) | bmw0[NB0][NW] u64   (host mirror: spec_lds_fixed_words_host)
 __host__ __device__ constexpr uint32_t spec_lds_fixed_words(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
-  return (((uint32_t)(K > 0 ? K : 1) + 3) & ~3u) * (uint32_t)nw + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
+  return (((uint32_t)(K > 0 ? K : 1) + 3) & ~3u) * (uint32_t)(nw + 1) + 128u + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * kBmWords) +
          (ndense > 0 ? (uint32_t)(nw * kDenseCap) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
 }
 
@@ -179,6 +179,7 @@ struct TileOf {
 template <class S>
 struct SpecSmem {
   uint32_t* wtot;
+  uint32_t* gbx;       // [KP + 128] single-pass form: the tile's chunk-relative base per counter, from the look-back wave to every wave; its exchange area
   uint32_t* nullcnt;
   uint32_t* nullw;
   uint32_t* misc;
@@ -189,6 +190,7 @@ struct SpecSmem {
   __device__ __forceinline__ SpecSmem(const KParams& P, uint8_t* smem) {
     uint32_t* p = reinterpret_cast<uint32_t*>(smem);
     wtot = p; p += (((S::K > 0 ? S::K : 1) + 3) & ~3) * (S::TILE / 64);
+    gbx = p; p += (((S::K > 0 ? S::K : 1) + 3) & ~3) + 128;      // + the look-back wave's exchange area [64][2]
     nullcnt = p; p += ((S::NNODES + 3) & ~3);
     nullw = p; p += ((S::NNODES * (S::TILE / 64) + 3) & ~3);
     misc = p; p += 4;
@@ -542,6 +544,257 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
     });
   }
 
+  RH_MARK(9);
+  RH_MARK_FLUSH;
+}
+
+// --------------------------------------------------------------------------
+// Single-pass form: size walk, scan across tiles and emit walk in ONE launch.
+//
+// The two-pass path reads every record twice from HBM (and moves 24 bytes of counters per record between the passes) only
+// because a tile cannot place its variable-length output before it knows what all tiles in front of it produce.  Here a
+// workgroup stages its window once, sizes it (the size pass's walk), publishes its K totals and LOOKS BACK over the tiles
+// in front of it in its chunk for their totals / inclusive prefixes (decoupled look-back), then emits out of the same
+// window.  What makes that work on an 8-XCD part:
+//   * state words are self-contained 64-bit values (status in the top bits, a 32-bit value below), written and polled with
+//     RELAXED agent-scope atomics -- no release / acquire fence anywhere, so no L2 write-back per tile (the fences of round
+//     1's attempt wrote the XCD's dirty output lines back at every tile: 4-7 ms);
+//   * tiles are handed out by a ticket per chunk in the order workgroups START, so the tile a workgroup waits for is
+//     always resident or finished -- no assumption about dispatch order or placement;
+//   * workgroup b works on chunk b % k: with the usual k = 8 chunks a chunk's tiles (and their state words, and the
+//     partial lines of its output buffers) stay on one XCD.
+// The arena is laid out from per-column CAPACITIES (the schema's history, KParams::caps) before the launch; a tile that
+// would leave its column's capacity raises LF_CAPACITY and emits nothing, and the host repeats the call on the two-pass
+// path -- as it does for a schema's first call, for the generic kernels and for offsets / indices beyond 32 bits.
+// --------------------------------------------------------------------------
+constexpr unsigned long long kLbAgg = 1ull << 62, kLbInc = 2ull << 62;
+
+template <class S>
+__device__ __forceinline__ void spec_fused(const KParams& P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;      // the capacity layout was refused: nothing to emit
+  const SpecSmem<S> s(P, smem);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  RH_MARK_INIT;
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW, KP = SCtx<S>::KP;
+#ifndef RH_V_NOPRIO
+  // Everything up to the look-back is on the critical path of every LATER tile of the chunk (they wait for this tile's
+  // totals): those phases run at raised wave priority, the emit walk (nobody waits for it) at the default.
+  __builtin_amdgcn_s_setprio(3);
+#endif
+  // ---- which tile: chunk = b % k, tile of the chunk = the chunk's next ticket
+  const uint32_t chunk = blockIdx.x % P.k;
+  const uint64_t rows_c = chunk == P.k - 1 ? P.rows_last : P.sz;
+  const uint32_t tiles_c = (uint32_t)((rows_c + T - 1) / T);
+  if (blockIdx.x / P.k >= tiles_c) return;                                  // (the grid is k x the longest chunk)
+  if (tid == 0) {
+    s.misc[3] = __hip_atomic_fetch_add(&P.tickets[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s.misc[0] = 0xFFFFFFFFu; s.misc[1] = 0; s.misc[2] = 0;
+  }
+  for (int i = tid; i < S::NNODES; i += T) s.nullcnt[i] = 0;
+  for (int i = tid; i < S::NNODES * NW; i += T) s.nullw[i] = 0;
+  for (int i = tid; i < S::NBM * kBmWords; i += T) s.bm[i] = 0;
+  __syncthreads();
+  RH_MARK(0);
+  const uint32_t lb = s.misc[3];
+  const uint32_t tile = chunk * P.bpc + lb;
+  Geo g;
+  g.chunk = chunk; g.lrow0 = lb * T; g.rec0 = (uint64_t)chunk * P.sz + g.lrow0;
+  { const uint64_t left = rows_c - g.lrow0; g.nrec = left < (uint64_t)T ? (uint32_t)left : (uint32_t)T; }
+  uint64_t o0 = 0, o1 = 0;
+  if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
+  const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
+  const uint64_t wb16 = wb & ~15ull;
+  const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
+  if (fits) stage_window<T>(P, s.win, wb16, we, tid);
+  __syncthreads();
+  RH_MARK(1);
+
+  // ---- size walk (the size pass's: fast form, a wave with an anomaly walks again carefully)
+  Lane L;
+  SCtx<S> c;
+  spec_ctx_init(c, P, s, g, tid);
+  c.bufp = (const __attribute__((address_space(4))) uint64_t*)(reinterpret_cast<uintptr_t>(P.bufptr) + (size_t)chunk * S::NBUF * 8);
+  lane_init_from(L, g, o0, o1, wb16, tid);
+  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
+  bool careful = !fits || P.all_careful != 0;
+  if constexpr (S::K > 0) {
+    spec_run_walk<S, false, false>(P, c, s.win, L, fits, wb16);
+    L.redo = L.redo || L.cur > L.end;
+    if (__any(L.redo)) {
+      careful = true;
+      spec_ctx_init(c, P, s, g, tid);
+      lane_init_from(L, g, o0, o1, wb16, tid);
+      if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
+      spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
+    }
+    RH_MARK(2);
+    if (lane == 0 && careful) atomicOr(&s.misc[2], 2u);       // one wave walked carefully: the whole tile emits carefully
+    // ---- wave scan of the K counters (two per dword when they all fit 10 bits: see spec_emit)
+    uint32_t allor = 0;
+    static_for<0, S::K>([&](auto ik) { allor |= c.cnt[decltype(ik)::value]; });
+    if (!__any(allor > 1023u)) {
+      constexpr int NDW = (S::K + 1) / 2;
+      uint32_t tot[KP] = {};
+      static_for<0, NDW>([&](auto id) {
+        constexpr int d = decltype(id)::value;
+        uint32_t v = c.cnt[2 * d];
+        if constexpr (2 * d + 1 < S::K) v |= c.cnt[2 * d + 1] << 16;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        const uint32_t ex = incl - v;
+        c.cnt[2 * d] = ex & 0xFFFFu;
+        tot[2 * d] = incl & 0xFFFFu;
+        if constexpr (2 * d + 1 < S::K) { c.cnt[2 * d + 1] = ex >> 16; tot[2 * d + 1] = incl >> 16; }
+      });
+      if (lane == 63) {
+        static_for<0, KP / 4>([&](auto iq) {
+          constexpr int q = decltype(iq)::value;
+          v4w x; x.x = tot[4 * q]; x.y = tot[4 * q + 1]; x.z = tot[4 * q + 2]; x.w = tot[4 * q + 3];
+          *reinterpret_cast<v4w*>(s.wtot + wave * KP + 4 * q) = x;
+        });
+      }
+    } else {
+      static_for<0, S::K>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        const uint32_t v = c.cnt[k];
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s.wtot[wave * KP + k] = incl;
+        c.cnt[k] = incl - v;
+      });
+    }
+  }
+  // errors of the size walk (malformed records): reported like the size pass does; the tile still takes part in the scan
+  if (L.err) atomicMin(&s.misc[0], tid);
+  RH_MARK(3);
+  __syncthreads();                                            // wtot, misc[0], misc[2]
+  RH_MARK(4);
+  if (s.misc[0] == tid) {
+    ErrInfo ei; ei.code = L.err; ei.pad = 0; ei.detail = L.edetail;
+    P.errinfo[tile] = ei;
+    atomicMax(P.first_bad, ~(unsigned long long)(g.rec0 + tid));
+  }
+  careful = careful || (s.misc[2] & 2u) != 0 || s.misc[0] != 0xFFFFFFFFu;
+
+  // ---- look-back (wave 0): this tile's totals out, the chunk-relative prefix of the tiles in front in.  Lane (j, k) polls
+  //      counter k's word of the (back + j)-th tile in front, NJ = 64 / K tiles per step: the tiles right in front are usually
+  //      still at their totals and an inclusive prefix sits a few tiles back, so a step -- ONE round trip to the memory side
+  //      -- normally ends the search, where walking back tile by tile paid a round trip per tile (~9 k cycles per tile,
+  //      profiles/r04p_*).  Lane k then adds the step's words up to the first inclusive one.
+  if constexpr (S::K > 0) {
+    if (wave == 0) {
+      static_assert(S::K <= 64, "the look-back wave holds one lane per counter");
+      constexpr uint32_t NJ = 64 / S::K;
+      const uint32_t k_of = lane % (uint32_t)S::K, j_of = lane / (uint32_t)S::K;
+      const bool in_grid = j_of < NJ;
+      uint32_t agg = 0;
+      if (lane < (uint32_t)S::K)
+        for (int w = 0; w < NW; w++) agg += s.wtot[w * KP + lane];
+      unsigned long long* const mine = P.lookback + (size_t)tile * S::K + k_of;
+      if (lane < (uint32_t)S::K)
+        __hip_atomic_store(mine, (lb == 0 ? kLbInc : kLbAgg) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t excl = 0;
+      bool found = lb == 0, stuck = false;
+      uint32_t* const xw = s.gbx + KP;                        // [64][2] exchange area of the look-back wave
+      for (uint32_t back = 1;; back += NJ) {
+        if (!__any(lane < (uint32_t)S::K && !found)) break;
+        uint32_t val = 0, st = 2;                             // in front of the chunk's first tile: an inclusive 0
+        const uint32_t dist = back + j_of;
+        if (in_grid && dist <= lb) {
+          const unsigned long long* q = mine - (size_t)dist * S::K;
+          unsigned long long w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (the tile polled holds an earlier ticket of this chunk: its workgroup is running or done, so the word WILL come.
+          //  The bound -- seconds -- only keeps a fault elsewhere from turning into a hung GPU: the call then fails over to
+          //  the two-pass path through LF_CAPACITY.)
+          for (uint32_t spins = 0; (w >> 62) == 0 && spins < (1u << 24); spins++) {
+            __builtin_amdgcn_s_sleep(1);
+            w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if ((w >> 62) == 0) { stuck = true; w = kLbInc; }
+          val = (uint32_t)w; st = (uint32_t)(w >> 62);
+        }
+        if (in_grid) { xw[2 * lane] = val; xw[2 * lane + 1] = st; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (a wave's DS instructions execute in order)
+        if (lane < (uint32_t)S::K && !found) {
+          for (uint32_t j = 0; j < NJ && !found; j++) {
+            excl += xw[2 * (j * S::K + lane)];
+            found = xw[2 * (j * S::K + lane) + 1] == 2u;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+      uint32_t over = 0;
+      if (lane < (uint32_t)S::K) {
+        if (lb != 0) __hip_atomic_store(mine, kLbInc | (unsigned long long)(uint32_t)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t end = (uint64_t)excl + agg;
+        over = end > P.caps[(size_t)lane * P.k + chunk] ? 1u : 0u;
+        if (lb == tiles_c - 1) P.totals[(size_t)lane * P.k + chunk] = end;
+        s.gbx[lane] = excl;                                   // chunk-relative base of this tile, per counter
+      }
+      if (__any(over != 0 || stuck)) {
+        if (lane == 0) {
+          s.misc[1] = 1;
+          atomicOr(reinterpret_cast<uint32_t*>(P.first_bad) + 2, (uint32_t)LF_CAPACITY);
+        }
+      }
+    }
+    RH_MARK(5);
+    __syncthreads();
+    RH_MARK(6);
+    if (s.misc[1] != 0) return;                               // over capacity: the host repeats the call on the two-pass path
+    static_for<0, S::K>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      c.gb[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.gbx[k]);
+    });
+    if constexpr (NW > 1) {
+      uint32_t prev = 0;
+      if (lane < (uint32_t)S::K) {
+        for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + lane] : 0u;
+      }
+      static_for<0, S::K>([&](auto ik) {
+        constexpr int k = decltype(ik)::value;
+        c.cnt[k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+      });
+    }
+  }
+
+  // ---- emit walk out of the same window
+#ifndef RH_V_NOPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  RH_MARK(7);
+  lane_init_from(L, g, o0, o1, wb16, tid);
+  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
+  if (careful) {
+    spec_run_walk<S, true, true>(P, c, s.win, L, fits, wb16);
+  } else {
+    spec_run_walk<S, true, false>(P, c, s.win, L, fits, wb16);
+    if (L.redo) L.err = E_INTERNAL;
+  }
+  RH_MARK(8);
+  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
+  __syncthreads();
+  report_errors(P, s.misc, L, g, tid, tile);
+  for (int i = tid; i < S::NNODES; i += T) {
+    uint32_t v = s.nullcnt[i];
+    for (int w = 0; w < NW; w++) v += s.nullw[i * NW + w];
+    if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * P.null_slots + (tile & (P.null_slots - 1))], v);
+  }
+  if constexpr (S::NB0 > 0) {
+    for (uint32_t i = tid; i < (uint32_t)(S::NB0 * NW); i += T) {
+      const uint32_t slot = i / NW, w = i % NW;
+      if (w * 64u < g.nrec) st_global<uint64_t, false>(c.buf(S::bm0buf(slot)), (g.lrow0 >> 6) + w, c.bmw0[i]);
+    }
+  }
+  if constexpr (S::NBM > 0) {
+    static_for<0, S::NBM>([&](auto ib) {
+      constexpr int slot = decltype(ib)::value;
+      const uint32_t w0 = c.gb[S::bmdom(slot) - 1] >> 5;
+      for (int w = tid; w < kBmWords; w += T) {
+        const uint32_t v = s.bm[slot * kBmWords + w];
+        if (v) atomic_or_global(c.buf(S::bmbuf(slot)), (uint64_t)w0 + w, v);
+      }
+    });
+  }
   RH_MARK(9);
   RH_MARK_FLUSH;
 }

@@ -25,7 +25,7 @@ std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile,
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
 inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {
-  return (((uint32_t)(K > 0 ? K : 1) + 3) & ~3u) * (uint32_t)nw + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * 64) +
+  return (((uint32_t)(K > 0 ? K : 1) + 3) & ~3u) * (uint32_t)(nw + 1) + 128u + (uint32_t)((nnodes + 3) & ~3) + (uint32_t)((nnodes * nw + 3) & ~3) + 4 + (uint32_t)(nbm * 64) +
          (ndense > 0 ? (uint32_t)(nw * 128) : 0u) + (((uint32_t)(nb0 * nw * 2) + 3) & ~3u);
 }
 // domain-0 bitmap buffers of a schema (their words are collected per tile in LDS by the specialised emit kernel)

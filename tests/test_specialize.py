@@ -15,9 +15,14 @@ def test_generated_source_follows_the_schema_program():
     assert '#include "spec_body.h"' in src and "rh_spec_size" in src and "rh_spec_emit" in src
     # full schema (scripts/generate_avro.py): 2 list loops (emails, phone_numbers), one 4-variant union, 2 nullable records
     assert src.count("h_list_begin<EMIT, CAREFUL>") == 2 and src.count("for (;;)") == 2
-    assert src.count("h_union_begin<EMIT, CAREFUL>") == 1 and src.count("h_variant(") == 4
-    assert src.count("h_rec_begin<EMIT, CAREFUL>") == 2 and src.count("h_rec_end(L)") == 2
+    assert src.count("h_union_begin<EMIT, CAREFUL") == 1 and src.count("h_variant(") == 4
+    assert src.count("h_rec_begin<EMIT, CAREFUL") == 2 and src.count("h_rec_end(L)") == 2
     assert "static constexpr int K = 12, NDOM = 3" in src
+    # head fusion (walk.h read_head LA): the two record branch bytes open a 4-byte chain (2 | 4 << 2 = 18) that the record's
+    # first string ends (1); the boolean in front of the union opens an 8-byte one (2 | 8 << 2 = 34) through the union index
+    # (3) into the first head of each of its three non-null variants (1)
+    assert src.count("h_rec_begin<EMIT, CAREFUL, 18>") == 2 and src.count("h_fixed<EMIT, CAREFUL, 34>") == 1
+    assert src.count("h_union_begin<EMIT, CAREFUL, 3>") == 1 and src.count("CAREFUL, 1>(c, src, L, op)") == 5
     flat = cabi.kernel_source(SCHEMAS["flat4"])
     assert "static constexpr int K = 0, NDOM = 1" in flat and flat.count("h_fixed<EMIT, CAREFUL>") == 4
 
