@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch brings its own HIP runtime; whichever runtime touches the GPU first in a process keeps it.  The engine is built
+    # to share torch's (bench.py and smoke() import torch first), so the test session does the same whatever order the test
+    # files run in: initialise torch's runtime before libruhvro_hip.so makes its first HIP call.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:      # no torch / no GPU: the CPU suite does not need it
+        pass
 
 
 @pytest.fixture(scope="session", autouse=True)
