@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "pyruhvro_amd", "csrc")
 HEADERS = ["program.h", "walk.h", "kernel_common.h", "spec_body.h", "encode.h", "encode_walk.h", "encode_spec.h"]
-KERNELS = {"emit": "rh_spec_emit", "size": "rh_spec_size", "eemit": "rh_espec_emit", "esize": "rh_espec_size"}
+KERNELS = {"emit": "rh_spec_emit", "fused": "rh_spec_fused", "size": "rh_spec_size", "eemit": "rh_espec_emit", "esize": "rh_espec_size"}
 
 
 def function_ranges(path):
@@ -58,7 +58,7 @@ def main():
     from avrogen.schemas import SCHEMAS
     from pyruhvro_amd import cabi
     schema = SCHEMAS.get(args.schema) or open(args.schema).read()
-    src = cabi.encode_kernel_source(schema) if args.kernel.startswith("e") and args.kernel != "emit" else cabi.kernel_source(schema)
+    src = cabi.encode_kernel_source(schema) if args.kernel in ("eemit", "esize") else cabi.kernel_source(schema)
     tmp = tempfile.mkdtemp(prefix="isa_hist_")
     try:
         for h in HEADERS:
