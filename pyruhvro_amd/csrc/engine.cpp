@@ -9,6 +9,7 @@
 // decode entry point fails with RH_ERR_RUNTIME.
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <pthread.h>
 
 // <hip/hip_ext.h> needs the HIP compiler; this translation unit is also built by g++ (sanitizer build).  The one
 // function used from it, as declared there:
@@ -1875,6 +1876,67 @@ class CallPool {
   bool stop_ = false;
 };
 
+// The gather pool and the shard streams of a pipelined host call are KEPT between calls: starting 32 threads while the caller's
+// extractor threads are busy took 2.5 ms of a 9 ms call (1M records through the Python surface, RUHVRO_HIP_TIMELINE,
+// profiles/r04zc_*); a second concurrent host call gets a pool of its own (at most two idle ones are kept).  A forked child starts
+// empty (the threads do not exist there): the cached objects are abandoned, never used.
+struct HostCallCache {
+  std::mutex mu;
+  std::vector<std::unique_ptr<CallPool>> pools;
+  std::vector<std::pair<int, hipStream_t>> streams;
+  static HostCallCache& get() {
+    static HostCallCache* c = [] {
+      HostCallCache* x = new HostCallCache();      // (never destroyed: worker threads may outlive static destruction order)
+      pthread_atfork(nullptr, nullptr, [] {
+        HostCallCache& h = get();
+        new (&h.mu) std::mutex();
+        for (auto& p : h.pools) (void)p.release();
+        h.pools.clear();
+        h.streams.clear();
+      });
+      return x;
+    }();
+    return *c;
+  }
+  std::unique_ptr<CallPool> take_pool(unsigned workers) {
+    {
+      std::lock_guard<std::mutex> l(mu);
+      for (size_t i = 0; i < pools.size(); i++)
+        if (pools[i]->workers() == workers) {
+          std::unique_ptr<CallPool> p = std::move(pools[i]);
+          pools.erase(pools.begin() + (long)i);
+          return p;
+        }
+    }
+    return std::unique_ptr<CallPool>(new CallPool(workers));
+  }
+  void give_pool(std::unique_ptr<CallPool> p) {
+    std::lock_guard<std::mutex> l(mu);
+    if (pools.size() < 2) pools.push_back(std::move(p));
+  }
+  hipStream_t take_stream(int device) {
+    {
+      std::lock_guard<std::mutex> l(mu);
+      for (size_t i = 0; i < streams.size(); i++)
+        if (streams[i].first == device) {
+          hipStream_t st = streams[i].second;
+          streams.erase(streams.begin() + (long)i);
+          return st;
+        }
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+  }
+  void give_stream(int device, hipStream_t st, bool idle) {
+    if (idle) {
+      std::lock_guard<std::mutex> l(mu);
+      if (streams.size() < 16) { streams.emplace_back(device, st); return; }
+    }
+    (void)hipStreamDestroy(st);
+  }
+};
+
 // Record slices [r0, r0 + n) gathered into pooled PINNED memory together with their offsets, laid out exactly like the
 // device staging buffer: [16 bytes lead][payload][pad to kAlign][u64 offsets n+1].
 struct Gathered {
@@ -2234,7 +2296,13 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
   const bool pregather = src.slices() || stage_packed;
   if (pregather) {
     gatherer = std::thread([&] {
-      CallPool pool(pack_threads);
+      struct PoolLoan {
+        std::unique_ptr<CallPool> p;
+        explicit PoolLoan(unsigned w) : p(HostCallCache::get().take_pool(w)) {}
+        ~PoolLoan() { HostCallCache::get().give_pool(std::move(p)); }
+      } loan(pack_threads);
+      CallPool& pool = *loan.p;
+      Timeline::mark(0, "gather pool up");
       auto par = [&](unsigned nt, const std::function<void(unsigned)>& f) { pool.parallel_for(nt, f); };
       for (size_t g = 0; g < ns; g++) {
         const Shard& sh = shards[g];
@@ -2243,7 +2311,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
           if (sh.c1 > sh.c0) {
             HIPCHK(hipSetDevice(sh.device));
             const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
-            if (streaming) wait_ready(r1);
+            if (streaming) { wait_ready(r1); Timeline::mark((uint32_t)g, "entries ready"); }
             ready.block[g] = src.slices() ? gather_slices(src, r0, r1 - r0, sh.device, pack_threads, par)
                                           : stage_packed_range(src, r0, r1 - r0, sh.device, pack_threads, par);
             if (gathered_ctr) __atomic_store_n(gathered_ctr, r1, __ATOMIC_RELEASE);   // (shards are gathered in row order)
@@ -2273,7 +2341,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
       try {
         if (sh.c1 > sh.c0) {             // an empty shard (k < g) only passes its gates
           HIPCHK(hipSetDevice(sh.device));
-          HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+          st = HostCallCache::get().take_stream(sh.device);
           const uint64_t r0 = (uint64_t)sh.c0 * sz, r1 = sh.c1 == k ? n : (uint64_t)sh.c1 * sz;
           ChunkGeo geo;
           geo.k = sh.c1 - sh.c0;
@@ -2297,7 +2365,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
       }
       h2d_gates[sh.gate].finish(sh.ticket);
       d2h_gates[sh.gate].finish(sh.ticket);
-      if (st) (void)hipStreamDestroy(st);
+      if (st) HostCallCache::get().give_stream(sh.device, st, !failed[g]);      // (a shard that succeeded has waited for its stream)
     });
   }
   for (auto& t : th) t.join();
