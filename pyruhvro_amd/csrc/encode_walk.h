@@ -205,8 +205,8 @@ __device__ __forceinline__ bool ld_bit(const Ctx& c, int buf, uint32_t r) {     
 }
 
 template <class Ctx>
-__device__ __forceinline__ FixedV e_fixed_load(const Ctx& c, const Op op) {
-  const uint32_t r = c.row(op.dom);
+__device__ __forceinline__ FixedV e_fixed_load(const Ctx& c, const Op op, uint32_t ahead = 0) {      // ahead: rows in front of the cursor
+  const uint32_t r = c.row(op.dom) + ahead;
   FixedV v;
   v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
   if (op.a == FK_I32) v.bits = (uint64_t)(int64_t)reinterpret_cast<const RH_GLOBAL int32_t*>(c.in(op.buf1))[r];
@@ -217,8 +217,8 @@ __device__ __forceinline__ FixedV e_fixed_load(const Ctx& c, const Op op) {
 }
 
 template <class Ctx>
-__device__ __forceinline__ SpanV e_span_load(const Ctx& c, const Op op) {        // string / enum / list / map offsets
-  const uint32_t r = c.row(op.dom);
+__device__ __forceinline__ SpanV e_span_load(const Ctx& c, const Op op, uint32_t ahead = 0) {        // string / enum / list / map offsets
+  const uint32_t r = c.row(op.dom) + ahead;
   SpanV v;
   v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
   const RH_GLOBAL uint32_t* off = reinterpret_cast<const RH_GLOBAL uint32_t*>(c.in(op.buf1));
@@ -234,11 +234,11 @@ __device__ __forceinline__ SpanV e_span_load(const Ctx& c, const Op op) {       
 }
 
 template <class Ctx>
-__device__ __forceinline__ bool e_rec_load(const Ctx& c, const Op op) { return ld_bit(c, op.buf0, c.row(op.dom)); }
+__device__ __forceinline__ bool e_rec_load(const Ctx& c, const Op op, uint32_t ahead = 0) { return ld_bit(c, op.buf0, c.row(op.dom) + ahead); }
 
 template <class Ctx>
-__device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op) {
-  return reinterpret_cast<const RH_GLOBAL int8_t*>(c.in(op.buf1))[c.row(op.dom)];
+__device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op, uint32_t ahead = 0) {
+  return reinterpret_cast<const RH_GLOBAL int8_t*>(c.in(op.buf1))[c.row(op.dom) + ahead];
 }
 
 // SURVEY 8(f) N4 (beyond the reference, whose encoder gate is false for these types): fixed(N),
@@ -246,8 +246,8 @@ __device__ __forceinline__ int32_t e_union_load(const Ctx& c, const Op op) {
 struct BinV { uint64_t lo, hi; bool valid; };
 
 template <class Ctx>
-__device__ __forceinline__ BinV e_bin_load(const Ctx& c, const Op op) {
-  const uint32_t r = c.row(op.dom);
+__device__ __forceinline__ BinV e_bin_load(const Ctx& c, const Op op, uint32_t ahead = 0) {
+  const uint32_t r = c.row(op.dom) + ahead;
   BinV v;
   v.lo = 0; v.hi = 0;
   v.valid = (op.flags & F_NULLABLE) ? ld_bit(c, op.buf0, r) : true;
