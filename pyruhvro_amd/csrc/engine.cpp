@@ -127,6 +127,7 @@ class Pool {
         Block b = free_[best];
         free_.erase(free_.begin() + best);
         cached_ -= b.size;
+        poison(b);
         return b;
       }
     }
@@ -139,7 +140,18 @@ class Pool {
       e = host_ ? hipHostMalloc(&b.p, size, hipHostMallocDefault) : hipMalloc(&b.p, size);
     }
     if (e != hipSuccess) throw HipError(std::string("HIP allocation of ") + std::to_string(size) + " bytes failed: " + hipGetErrorString(e));
+    poison(b);
     return b;
+  }
+  // RUHVRO_HIP_POISON=1 (test mode): every block is handed out filled with 0xA5, so that nothing can lean on what a block
+  // happens to hold -- fresh allocations read as zero, which hides a read of padding or of a slot nobody wrote until the
+  // pool hands out used memory (the encode kernels' look-ahead found that way: profiles/r04zg_*).  Slow: a synchronous fill.
+  void poison(const Block& b) const {
+    static const bool on = [] { const char* e = std::getenv("RUHVRO_HIP_POISON"); return e && *e && *e != '0'; }();
+    if (!on || !b.p) return;
+    if (host_) { std::memset(b.p, 0xA5, b.size); return; }
+    (void)hipMemset(b.p, 0xA5, b.size);
+    (void)hipDeviceSynchronize();
   }
   // A cached block of a suitable size, or an empty Block: never allocates.
   Block try_get(uint64_t size, int device) {
@@ -153,6 +165,7 @@ class Pool {
     Block b = free_[best];
     free_.erase(free_.begin() + best);
     cached_ -= b.size;
+    poison(b);
     return b;
   }
   void put(Block b) {

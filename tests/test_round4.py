@@ -8,6 +8,7 @@
   step is the ordered join of ruhvro/src/deserialize.rs:115-119; ours is stats only);
 * the bench line carries `parity_check` for its own timed configuration;
 * RUHVRO_HIP_NO_TRUST=1 (the emit pass keeps its own bounds / anomaly checks in every tile) produces the same buffers;
+* RUHVRO_HIP_POISON=1 (pooled memory handed out as 0xA5): both directions still produce the oracle's bytes;
 * the CPython boundary resolves "current device" on the calling thread.
 """
 import json
@@ -99,6 +100,20 @@ def test_bench_line_carries_parity_evidence_for_its_timed_configuration():
 def test_no_trust_knob_same_buffers():
     """RUHVRO_HIP_NO_TRUST=1: every tile of the emit pass is walked with its own checks (read once per process)."""
     env = dict(os.environ, RUHVRO_HIP_NO_TRUST="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_quick.py"), "200000"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "parity ok" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_poisoned_pools_both_directions():
+    """RUHVRO_HIP_POISON=1: every pooled block (device arena, workspaces, pinned staging) is handed out filled with 0xA5, so
+    a kernel that reads padding or a slot nobody wrote gets garbage instead of the zeros of a fresh allocation -- how the
+    encode kernels' look-ahead read was found (profiles/r04zg_*).  The encode suite's nested / generated cases and the decode
+    parity core run under it in a process of their own (the switch is read once)."""
+    env = dict(os.environ, RUHVRO_HIP_POISON="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_encode.py", "-m", "gpu", "-q", "-x", "-k",
+                        "nested or generated or random or round_trip"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2500:] + p.stderr[-1500:]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_quick.py"), "200000"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "parity ok" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
