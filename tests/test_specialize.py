@@ -62,6 +62,24 @@ def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
         cabi.encode_kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"long","logicalType":"timestamp-nanos"}}]}')
 
 
+def test_encode_list_bodies_are_software_pipelined_with_a_guarded_look_ahead(monkeypatch):
+    """Round 4: inside a list loop the first-level loads of the NEXT item are issued at the top of an iteration, and a top-level
+    list's first item is requested in front of the loop with the row's string fetches.  The look-ahead is per lane and only
+    taken with two or more items left: row + 1 may lie behind the column, where an offsets slot holds padding (that read
+    faulted once the arena pool handed out used memory: profiles/r04zg_*)."""
+    src = cabi.encode_kernel_source(SCHEMAS["full"])
+    body = src[src.index("static __device__ __forceinline__ void walk"):]
+    # emails (one string per item) and phone_numbers (key + value): three look-ahead loads, each guarded, each preloaded once
+    assert body.count("c.rem(0) > 1u ? 1u : 0u") == 3
+    assert body.count("= e_span_load(c, op4, v2.s0);") == 1 and body.count("= e_span_load(c, op14, v12.s0);") == 1
+    loop = body[body.index("for (;;) {"):]
+    assert loop.index("const SpanV v4 = nv4;") < loop.index("nv4 = e_span_load(c, op4,") < loop.index("e_string_fetch<MODE>(c, op4, v4)")
+    assert ", 1u)" not in body                          # never an unconditional row + 1
+    monkeypatch.setenv("RUHVRO_HIP_NO_ENC_PIPE", "1")    # the A/B knob generates the loop of round 3
+    old = cabi.encode_kernel_source(SCHEMAS["full"])
+    assert "nv4" not in old and old.count("for (;;) {") == 2
+
+
 def test_unsupported_schema_has_no_kernel():
     with pytest.raises(ValueError):
         cabi.kernel_source('{"type":"record","name":"B","fields":[{"name":"b","type":{"type":"long","logicalType":"local-timestamp-micros"}}]}')
