@@ -323,6 +323,39 @@ def test_device_resident_encode(name, n, k, kernel):
     r.free()
 
 
+def test_device_resident_round_trip_at_ten_million_rows(kernel):
+    """The bench's device-resident configuration at its full size, both directions back to back in HBM: 10M records of the
+    generate_avro.py schema -> rh_decode_device (8 chunks' worth in one batch) -> rh_encode_device on those buffers -> the
+    datums and offsets that went in, chunk by chunk (the generator writes the reference's single-block form, so
+    encode(decode(x)) == x byte for byte; fast_decode.rs:945-953 assert_round_trip is the reference's own form of this)."""
+    import ctypes as C
+    import hipmem
+    if kernel != cabi.KERNEL_SPECIALIZED:
+        pytest.skip("the full size runs on the kernels the bench times")
+    n, k = 10_000_000, 8
+    data, offsets = fastgen.generate("full", n)
+    d_data, d_off = hipmem.upload_packed(data, offsets)
+    r = cabi.decode_device(d_data.ptr, d_off.ptr, int(offsets[-1]), n, SCHEMAS["full"], 1, device=0, kernel=kernel)
+    view = r.export(0)
+    sch = cabi.schema_struct(SCHEMAS["full"])
+    enc = cabi.encode_device(C.addressof(view.array), C.addressof(sch), SCHEMAS["full"], k, device=0, kernel=kernel)
+    assert enc.stats["records"] == n and enc.chunks == k
+    pos = 0
+    for c in range(k):
+        d = enc.export(c)
+        rows = d.array.length
+        offs = hipmem.d2h(d.array.buffers[1], 4 * (rows + 1)).view(np.int32)
+        assert np.array_equal(offs.astype(np.uint64), offsets[pos: pos + rows + 1] - offsets[pos])
+        got = hipmem.d2h(d.array.buffers[2], int(offs[-1]))
+        assert np.array_equal(got, data[int(offsets[pos]): int(offsets[pos + rows])])
+        pos += rows
+        C.CFUNCTYPE(None, C.POINTER(cabi.ArrowArray))(d.array.release)(C.byref(d.array))
+    assert pos == n
+    C.CFUNCTYPE(None, C.POINTER(cabi.ArrowArray))(view.array.release)(C.byref(view.array))
+    enc.free()
+    r.free()
+
+
 def test_device_resident_encode_errors(kernel):
     """Data-dependent failures of the device-resident form carry the reference's text too (the enum symbol is fetched
     from HBM for the message, fast_encode.rs:576)."""
