@@ -84,6 +84,20 @@ def test_single_pass_at_one_million_records_full_buffer_identity():
     assert d["single_pass_calls"] == 3 and d["single_pass_failovers"] == 0
 
 
+def test_single_pass_at_ten_million_records_full_buffer_identity():
+    """The size bench.py times (BASELINE config 4): every buffer of every chunk of a single-pass call against the oracle."""
+    n, k = 10_000_000, 8
+    data, offsets = fastgen.generate("full", n)
+    exp = c_walker.decode_packed(c_walker.CompiledSchema(SCHEMAS["full"]), data, offsets, k, threaded=True)
+    res = _resident(data, offsets)
+    schema = SCHEMAS["full"] + "\r\n"             # (a schema object of its own)
+    _call(res, n, schema, k).free()                  # history
+    c0 = cabi.engine_counters()
+    _check(_call(res, n, schema, k, asynchronous=True), exp)
+    d = _delta(c0)
+    assert d["single_pass_calls"] == 1 and d["single_pass_failovers"] == 0
+
+
 def test_a_column_that_outgrows_its_capacity_fails_over_to_the_two_pass_form(monkeypatch):
     """History from short strings, then the same schema with strings several times as long: the single pass raises LF_CAPACITY
     (it writes nothing beyond a capacity), the call is repeated on the two-pass form, and the schema sits the next calls out
