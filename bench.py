@@ -605,6 +605,26 @@ def encode_line(args):
     total = ob - 4 * (n + k)                                   # Avro bytes (the result's exact bytes = i32 offsets + datums)
     if not os.environ.get("RUHVRO_HIP_VARIANT"):               # (a timing-only kernel variant of an A/B script may produce other bytes: its line is not a result)
         assert total == int(offsets[-1]), "re-encoded bytes differ in size from the generator's datums"
+    # parity evidence for this line's own configuration: one more call, its BinaryArrays copied to the host, datums and offsets
+    # against the generator's payload (the generator writes the reference's single-block form: encode(decode(x)) == x)
+    parity = None
+    if not os.environ.get("RUHVRO_HIP_VARIANT"):
+        tp = time.perf_counter()
+        enc = cabi.encode_device(C.addressof(view.array), C.addressof(sch), schema, k, device=0, stream=stream, kernel=kernel)
+        arrays = enc.to_host()
+        pos, same = 0, len(arrays) == k
+        for a in arrays:
+            o = np.frombuffer(a.buffers()[1], dtype=np.int32, count=len(a) + 1)
+            dd = np.frombuffer(a.buffers()[2], dtype=np.uint8, count=int(o[-1]))
+            same = same and np.array_equal(o.astype(np.uint64), offsets[pos: pos + len(a) + 1] - offsets[pos]) \
+                and np.array_equal(dd, data[int(offsets[pos]): int(offsets[pos + len(a)])])
+            pos += len(a)
+        same = bool(same and pos == n)
+        del arrays
+        enc.free()
+        parity = {"config": f"rh_encode_device on the timed stream, {n} rows, num_chunks={k}, every BinaryArray copied to the host after the timed region",
+                  "rows": n, "chunks": k, "result": "identical" if same else "DIFFERENT", "check_s": round(time.perf_counter() - tp, 2)}
+        assert same, "re-encoded datums differ from the generator's"
     alg = arrow_bytes + total + 4 * (n + k)                 # Arrow bytes in + Avro bytes out + i32 offsets out
     emit_ms = acc["emit_kernel_ms"]
     kern_ms = acc["size_kernel_ms"] + acc["scan_kernel_ms"] + emit_ms
@@ -638,6 +658,7 @@ def encode_line(args):
                      "algorithmic_bytes_per_launch": int(alg), "bytes_per_record": alg / n, "avg_launch_ms": emit_ms,
                      "timed_launches": sampled,
                      "path_frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kern_ms else 0.0},
+        "parity_check": parity,
         "end_to_end": {"value": n / best, "unit": "rows/s", "wall_ms": best * 1e3,
                        "what": "rh_encode: host RecordBatch in -> host BinaryArrays out (PCIe both ways), best of 3",
                        "stage_ms": {key: round(float(hst[key]), 3) for key in ("h2d_ms", "size_kernel_ms", "scan_kernel_ms", "emit_kernel_ms", "d2h_ms", "total_ms")}}})
@@ -691,7 +712,8 @@ def other_configs(local_rank: int = 0, steps: int = 60):
     enc = encode_line(argparse.Namespace(rows=2_000_000, steps=5, warmup=2, kernel="auto", stats_every=STATS_EVERY))
     out["encode_2m_rows"] = {"workload": enc["config"]["workload"], "ms_per_step": enc["ms_per_step"], "rows_per_s": enc["value"],
                              "kernel_ms": enc["config"]["kernel_ms"], "emit_frac": enc["roofline"]["frac"],
-                             "traffic": enc["roofline"]["traffic"], "end_to_end_rows_per_s": enc["end_to_end"]["value"]}
+                             "traffic": enc["roofline"]["traffic"], "end_to_end_rows_per_s": enc["end_to_end"]["value"],
+                             "parity_check": enc.get("parity_check")}
     return out
 
 
