@@ -85,6 +85,7 @@ def parse_args(argv=None):
                     help="streams of the second timed region reported as `overlapped` (0 = skip)")
     ap.add_argument("--sync-calls", action="store_true", help="every step waits for its own call (no RH_ASYNC pipelining)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the compact lines of BASELINE configs 2-3, full1m and encode")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip cold_start (a schema's first call against an empty kernel cache)")
     ap.add_argument("--no-projection", action="store_true", help="skip config5_projection (profiler passes: only full-size launches)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "specialized"])
     ap.add_argument("--cpu-sample", type=int, default=0, help="records of the CPU baseline (0 = the whole workload)")
@@ -179,11 +180,99 @@ def cpu_baseline(gen_cfg: str, schema_json: str, n_sample: int, num_chunks: int,
     if wide != num_chunks:
         out["wide"] = {"value": timed(wide), "unit": "records/s", "cores": wide,
                        "sample": f"same records, {wide} chunks = {wide} threads (what the reference would use with num_chunks={wide}), best of 5"}
+    out["reference"] = reference_probe()
+    # the same port at the metric's other sizes (BASELINE.json: 10k / 1M / 10M), the neighbours of end_to_end's Python-surface lines
+    out["at_metric_sizes"] = {}
+    for m in (10_000, 1_000_000):
+        if m < n_sample:
+            off_m = offsets[: m + 1]
+            best = float("inf")
+            for _ in range(6):
+                t = time.perf_counter()
+                c_walker.decode_packed(cs, data[: int(off_m[-1])], off_m, num_chunks, threaded=True, materialize=False)
+                best = min(best, time.perf_counter() - t)
+            out["at_metric_sizes"][str(m)] = {"value": m / best, "wall_ms": best * 1e3, "unit": "records/s", "cores": num_chunks}
     parity = None
     if parity_of is not None:       # (got batches, description) of one call of the timed GPU configuration on these same records
         got, config = parity_of
         parity = parity_check(cs, data, offsets, num_chunks, got, config)
     return out, parity
+
+
+def cold_start(gen_cfg: str, schema_json: str, n: int = 100_000, num_chunks: int = 8):
+    """What a NEW schema costs (the reference: a JSON parse, src/lib.rs:39-54).  An empty kernel cache and the compiler's own
+    cache off: the first n-record device-resident call of a fresh schema handle is served by the generic kernels while the
+    specialised pair compiles in helper processes (kernel_jobs.cpp); `compile_s` later the next call runs on them."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from avrogen import fastgen
+    from pyruhvro_amd import cabi
+    data, offsets = fastgen.generate(gen_cfg, n)
+    d_data = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+    d_data[: len(data)].copy_(torch.from_numpy(data))
+    d_off = torch.from_numpy(offsets.view(np.int64)).to("cuda")
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    args = (d_data.data_ptr(), d_off.data_ptr(), int(offsets[-1]), n)
+    tmp = tempfile.mkdtemp(prefix="rh_cold_")
+    saved = {k: os.environ.get(k) for k in ("RUHVRO_HIP_KERNEL_CACHE", "AMD_COMGR_CACHE")}
+    os.environ["RUHVRO_HIP_KERNEL_CACHE"] = tmp
+    os.environ["AMD_COMGR_CACHE"] = "0"          # (inherited by the compile helpers)
+    try:
+        fresh = schema_json + "\n\n"             # a schema handle of its own: nothing loaded, nothing remembered
+        t = time.perf_counter()
+        r = cabi.decode_device(*args, fresh, num_chunks, stream=stream)
+        first_ms = (time.perf_counter() - t) * 1e3
+        spec_first = int(r.stats["specialized"])
+        r.free()
+        t = time.perf_counter()
+        r = cabi.decode_device(*args, fresh, num_chunks, stream=stream)
+        second_ms = (time.perf_counter() - t) * 1e3
+        r.free()
+        t = time.perf_counter()
+        ready = cabi.kernels_ready(fresh, timeout_ms=300_000)
+        compile_s = time.perf_counter() - t
+        r = cabi.decode_device(*args, fresh, num_chunks, stream=stream)
+        spec_after = int(r.stats["specialized"])
+        r.free()
+        t = time.perf_counter()
+        r = cabi.decode_device(*args, fresh, num_chunks, stream=stream)
+        warm_ms = (time.perf_counter() - t) * 1e3
+        r.free()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"records": n, "cold_first_call_ms": first_ms, "specialized_first_call": spec_first, "second_call_ms": second_ms,
+            "compile_s": compile_s, "kernels_ready": bool(ready), "specialized_after": spec_after, "warm_call_ms": warm_ms,
+            "what": (f"fresh schema handle, empty kernel cache, AMD_COMGR_CACHE=0: first synchronous rh_decode_device of {n} records (generic "
+                     "kernels; rh_spec_size / rh_spec_emit start compiling in two rh_kcompile helper processes), the call after it, the "
+                     "wait until rh_schema_kernels_ready, and a call on the specialised kernels")}
+
+
+def reference_probe():
+    """the reference's own numbers need a Rust toolchain on the bench host (cargo bench -p ruhvro --bench
+    deserialize, ruhvro/benches/deserialize.rs:55-82; scripts/run_benchmarks.sh).  Probe for one; run the bench when it and the
+    reference tree are both there (never the case on the GPU box: /root/reference does not travel)."""
+    import shutil
+    import subprocess
+    cargo = shutil.which("cargo")
+    if not cargo:
+        return "unavailable (no cargo on this host)"
+    ref = os.environ.get("RUHVRO_REFERENCE_DIR", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "Cargo.toml")):
+        return f"unavailable (cargo at {cargo}, but no reference tree at {ref})"
+    try:
+        p = subprocess.run([cargo, "bench", "--offline", "-p", "ruhvro", "--bench", "deserialize"], cwd=ref, capture_output=True, text=True, timeout=900)
+        tail = [ln for ln in p.stdout.splitlines() if "time:" in ln or "thrpt:" in ln][-12:]
+        return {"rc": p.returncode, "lines": tail} if p.returncode == 0 else f"cargo bench failed (rc {p.returncode}): {p.stderr[-300:]}"
+    except Exception as e:      # noqa: BLE001 - reported in the line
+        return f"cargo bench did not run: {e}"
 
 
 def end_to_end(gen_cfg: str, schema_json: str, n: int, num_chunks: int):
@@ -926,6 +1015,8 @@ def main(argv=None):
             out["parity_check"] = parity
     if not args.no_end_to_end and world == 1:
         out["end_to_end"] = end_to_end(gen_cfg, SCHEMAS[gen_cfg], n, num_chunks)
+    if not args.no_cold_start and world == 1:
+        out["cold_start"] = cold_start(gen_cfg, SCHEMAS[gen_cfg])
     if not args.no_other_configs and not args.no_end_to_end and world == 1 and shard_whole:     # (profiler passes give --no-end-to-end)
         run.step = None            # (the 10M-record buffers of the main workload are not needed any more)
         out["other_configs"] = other_configs(0)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 5
+#define RH_ABI_VERSION 6
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -97,9 +97,14 @@ typedef struct {
 } rh_opts;
 
 /* Kernel selection (rh_opts.flags).  Both forms are HIP kernels running the same field handlers and
- * produce identical buffers; AUTO specialises the kernel to the schema when the call is large enough
- * to amortise a one-off compile (RUHVRO_HIP_SPECIALIZE_MIN records, default 32768) or when the code
- * object is already in the kernel cache, and uses the generic schema-program interpreter otherwise. */
+ * produce identical buffers.  AUTO uses the kernels specialised to the schema when their code objects
+ * are in the kernel cache, the generic schema-program interpreter otherwise -- and a call large enough
+ * to be worth it (RUHVRO_HIP_SPECIALIZE_MIN records, default 32768) that misses the cache starts the
+ * compile IN THE BACKGROUND (ABI version 6): that call and the ones after it run on the generic kernels
+ * at once, the first call after the compile jobs finish switches over (rh_stats.specialized says which
+ * form ran; rh_schema_kernels_ready waits for the switch).  A new schema therefore costs what it costs
+ * the reference (src/lib.rs:39-54: a parse), not a compile.  RH_KERNEL_SPECIALIZED insists: the call
+ * waits for the compile, or fails if there is no compiler. */
 #define RH_KERNEL_AUTO 0
 #define RH_KERNEL_GENERIC 1
 #define RH_KERNEL_SPECIALIZED 2
@@ -203,6 +208,12 @@ char* rh_schema_kernel_source(const rh_schema* s);
 char* rh_schema_kernel_key(const rh_schema* s, int encode);
 char* rh_schema_encode_kernel_source(const rh_schema* s);      /* the Arrow -> Avro pair (rh_encode) */
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err);
+/* ABI version 6.  State of the specialised decode (encode = 0) or encode (1) kernels of this schema: 1 = their code
+ * objects are there (the next call runs on them), 0 = not yet (still compiling after timeout_ms, or nobody asked for them:
+ * no call of RUHVRO_HIP_SPECIALIZE_MIN records yet and nothing in the kernel cache), -1 = the compile failed (*err).
+ * Waits up to timeout_ms for running compile jobs (0 = just look, < 0 = no limit).  A service that wants its first batch
+ * at full speed calls rh_schema_prebuild at start-up instead; this is for the ones that would rather start serving. */
+int rh_schema_kernels_ready(const rh_schema* s, int encode, long timeout_ms, char** err);
 
 /* Arrow -> Avro, the other direction.  Replaces ruhvro::serialize::serialize_record_batch
  * (ruhvro/src/serialize.rs:38-67) + fast_encode::serialize_chunk (ruhvro/src/fast_encode.rs:27-53): `batch` is
@@ -242,7 +253,8 @@ enum {
   RH_CTR_SPLIT_CALLS = 5,      /* device-resident calls that dealt their chunk groups to internal streams (in-call overlap) */
   RH_CTR_SINGLE_PASS_CALLS = 6, /* decode calls that took the single-pass form (one kernel sizes, scans across tiles and emits) */
   RH_CTR_SINGLE_PASS_FAILOVERS = 7, /* ... of which outgrew a column capacity and were repeated on the two-pass form */
-  RH_CTR_COUNT = 8
+  RH_CTR_BACKGROUND_COMPILES = 8, /* kernel compile jobs started behind a call that went ahead on the generic kernels (ABI 6) */
+  RH_CTR_COUNT = 9
 };
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 

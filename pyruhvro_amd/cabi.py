@@ -119,6 +119,8 @@ def lib():
         L.rh_schema_kernel_key.restype = C.c_void_p
         L.rh_schema_kernel_key.argtypes = [C.c_void_p, C.c_int]
         L.rh_schema_prebuild.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+        L.rh_schema_kernels_ready.restype = C.c_int
+        L.rh_schema_kernels_ready.argtypes = [C.c_void_p, C.c_int, C.c_long, C.POINTER(C.c_char_p)]
         L.rh_abi_version.restype = C.c_int
         L.rh_current_device.restype = C.c_int
         L.rh_device_count.restype = C.c_int
@@ -137,7 +139,7 @@ def lib():
     return _lib
 
 
-ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers")
+ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers", "background_compiles")
 
 
 def engine_counters() -> dict:
@@ -244,6 +246,16 @@ def prebuild(schema_json: str) -> bool:
     if rc != RH_OK:
         _raise(rc, err)
     return bool(cached.value)
+
+
+def kernels_ready(schema_json: str, encode: bool = False, timeout_ms: int = 0) -> bool:
+    """rh_schema_kernels_ready: True when the schema's specialised kernels are there (the next call runs on them), False while
+    their compile jobs are still running after `timeout_ms` (or nobody asked for them); raises when the compile failed."""
+    err = C.c_char_p()
+    rc = lib().rh_schema_kernels_ready(Schema.get(schema_json).handle, 1 if encode else 0, int(timeout_ms), C.byref(err))
+    if rc < 0:
+        _raise(RH_ERR_RUNTIME, err)
+    return rc == 1
 
 
 def shard_chunks(n: int, num_chunks: int, n_shards: int, shard: int):

@@ -37,6 +37,8 @@ extern "C" hipError_t hipExtModuleLaunchKernel(hipFunction_t f, uint32_t globalW
 #include "program.h"
 #include "schema.h"
 #include "specialize.h"
+#include "kernel_jobs.h"
+#include "rtc_compile.h"
 #include "encode.h"
 
 extern "C" {
@@ -290,11 +292,15 @@ struct DeviceProgram {
   int32_t* cnt_databuf = nullptr;
 };
 
-struct SpecKernel {      // schema-specialised k_size / k_emit loaded on one device
-  hipModule_t mod = nullptr;
+struct SpecKernel {      // schema-specialised kernels loaded on one device (each kernel is its own code object, kernel_jobs.h)
+  hipModule_t mod[3] = {nullptr, nullptr, nullptr};
   hipFunction_t size_fn = nullptr, emit_fn = nullptr;
-  hipFunction_t fused_fn = nullptr;      // the single-pass form (decode kernels only)
-  bool ok = false;
+  // the single-pass form (decode kernels only): compiled and loaded when a call first asks for it, so it is written while
+  // other calls of the schema read it
+  std::atomic<hipFunction_t> fused_fn{nullptr};
+  bool fused_dead = false;  // no such kernel for this schema (K > 64), or its compile failed
+  bool ok = false;          // size_fn and emit_fn are loaded
+  bool dead = false;        // they never will be: `why` says why (a failure is remembered)
   std::string why;
 };
 
@@ -304,8 +310,9 @@ struct rh_schema {
   std::unique_ptr<CompiledSchema> cs;
   std::mutex mu;
   std::map<int, DeviceProgram> dev;
-  std::map<int, SpecKernel> spec;
-  std::map<int, SpecKernel> espec;   // Arrow -> Avro kernels (rh_espec_size / rh_espec_emit)
+  std::map<int, std::unique_ptr<SpecKernel>> spec;
+  std::map<int, std::unique_ptr<SpecKernel>> espec;   // Arrow -> Avro kernels (rh_espec_size / rh_espec_emit)
+  std::shared_ptr<rh::KernelImages> images = rh::new_kernel_images();   // their code objects (device independent) + compile jobs
   // Arena bytes per (payload byte + 64 B per record) that the last decode of this schema needed: sizes the arena of
   // the next call BEFORE its totals are known, so that the call is one stream submission (decode_device_impl1).
   // 0 = no history yet (the first call of a schema lays its arena out on the host, after the scan).
@@ -352,37 +359,78 @@ uint64_t spec_min_records() {
   return v;
 }
 
-// Specialised kernels of this schema on `device`: code object from the kernel cache, or (allow_compile)
-// generated + compiled with hiprtc on the spot.  A failure is remembered (ok = false, why).
-const SpecKernel& spec_kernel(rh_schema* s, int device, bool allow_compile, bool encode = false) {
+hipFunction_t load_part(SpecKernel& k, int slot, const rh::KernelImage& im, int part) {
+  hipError_t e = hipModuleLoadData(&k.mod[slot], im.code->data());
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
+  hipFunction_t fn = nullptr;
+  e = hipModuleGetFunction(&fn, k.mod[slot], rh::kernel_part_entry(part));
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+  return fn;
+}
+
+// Specialised kernels of this schema on `device`.  Their code objects come from the kernel cache; on a miss the policy
+// decides: nothing (small calls), compile jobs in the background -- THIS call then runs on the generic kernels and a later
+// one finds the objects ready -- or wait for the jobs (RH_KERNEL_SPECIALIZED, an explicit request).  The schema's mutex is
+// only ever held for table look-ups and hipModuleLoadData, never across a compile.  `want_fused`: also the single-pass
+// kernel (compiled on first request).  A failure is remembered (dead, why).
+const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy, bool encode = false, bool want_fused = false) {
+  std::map<int, std::unique_ptr<SpecKernel>>& table = encode ? s->espec : s->spec;
+  SpecKernel* k = nullptr;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    std::unique_ptr<SpecKernel>& slot = table[device];
+    if (!slot) slot.reset(new SpecKernel);
+    k = slot.get();                                   // (entries are never removed while the schema lives)
+    if (k->dead) return *k;
+    if (k->ok && (!want_fused || k->fused_dead || k->fused_fn.load(std::memory_order_acquire))) return *k;
+  }
+  const int p_size = encode ? rh::KP_ESIZE : rh::KP_SIZE, p_emit = encode ? rh::KP_EEMIT : rh::KP_EMIT;
+  const unsigned parts = (1u << p_size) | (1u << p_emit) | ((want_fused && !encode) ? (1u << rh::KP_FUSED) : 0u);
+  rh::KernelImage im[rh::KP_COUNT];
+  const unsigned started = rh::kernel_images(s->images, *s->cs, parts, policy, im);     // (blocks only under CP_BLOCKING)
+  if (started && policy == rh::CP_BACKGROUND) g_counters[RH_CTR_BACKGROUND_COMPILES].fetch_add(started, std::memory_order_relaxed);
   std::lock_guard<std::mutex> g(s->mu);
-  std::map<int, SpecKernel>& table = encode ? s->espec : s->spec;
-  auto it = table.find(device);
-  if (it != table.end() && (it->second.ok || !allow_compile || it->second.why != "not cached")) return it->second;
-  SpecKernel k;
+  if (k->dead) return *k;
   try {
-    std::vector<char> image = rh::get_kernel_image(*s->cs, allow_compile, nullptr, encode);
-    if (image.empty()) {
-      k.why = "not cached";
-    } else {
-      hipError_t e = hipModuleLoadData(&k.mod, image.data());
-      if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleLoadData: ") + hipGetErrorString(e));
-      e = hipModuleGetFunction(&k.size_fn, k.mod, encode ? "rh_espec_size" : "rh_spec_size");
-      if (e == hipSuccess) e = hipModuleGetFunction(&k.emit_fn, k.mod, encode ? "rh_espec_emit" : "rh_spec_emit");
-      if (e != hipSuccess) throw std::runtime_error(std::string("hipModuleGetFunction: ") + hipGetErrorString(e));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.size_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.emit_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (!encode && hipModuleGetFunction(&k.fused_fn, k.mod, "rh_spec_fused") == hipSuccess)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k.fused_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      else k.fused_fn = nullptr;
-      (void)hipGetLastError();
-      k.ok = true;
+    if (!k->ok) {
+      for (int p : {p_size, p_emit})
+        if (im[p].state == rh::IMG_FAILED || im[p].state == rh::IMG_NONE) {
+          k->dead = true;
+          k->why = im[p].state == rh::IMG_NONE ? std::string("the schema has no such kernel") : im[p].why;
+          return *k;
+        }
+      if (im[p_size].state == rh::IMG_READY && im[p_emit].state == rh::IMG_READY) {
+        k->size_fn = load_part(*k, 0, im[p_size], p_size);
+        k->emit_fn = load_part(*k, 1, im[p_emit], p_emit);
+        k->ok = true;
+        k->why.clear();
+      } else {
+        k->why = (im[p_size].state == rh::IMG_COMPILING || im[p_emit].state == rh::IMG_COMPILING) ? "compiling" : "not cached";
+      }
+    }
+    if (k->ok && want_fused && !encode && !k->fused_dead && !k->fused_fn.load(std::memory_order_relaxed)) {
+      const rh::KernelImage& f = im[rh::KP_FUSED];
+      if (f.state == rh::IMG_FAILED || f.state == rh::IMG_NONE) k->fused_dead = true;
+      else if (f.state == rh::IMG_READY) k->fused_fn.store(load_part(*k, 2, f, rh::KP_FUSED), std::memory_order_release);
     }
   } catch (const std::exception& e) {
-    k.why = e.what();
+    k->dead = true;
+    k->ok = false;
+    k->why = e.what();
   }
-  table[device] = k;
-  return table[device];
+  return *k;
+}
+
+// What a call of `n` records may spend on kernels this schema does not have yet.
+rh::CompilePolicy compile_policy(int mode, uint64_t n) {
+  if (mode == RH_KERNEL_SPECIALIZED) return rh::CP_BLOCKING;
+  // RUHVRO_HIP_SYNC_COMPILE=1: the pre-ABI-6 behaviour -- a large call waits for its schema's compile (deterministic benchmarks
+  // of a cold process, nothing else)
+  static const bool sync = [] { const char* e = std::getenv("RUHVRO_HIP_SYNC_COMPILE"); return e && *e && *e != '0'; }();
+  if (n >= spec_min_records()) return sync ? rh::CP_BLOCKING : rh::CP_BACKGROUND;
+  return rh::CP_CACHED_ONLY;
 }
 
 int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream,
@@ -1044,10 +1092,19 @@ struct rh_decode_call {
   bool try_single(bool two_sync, long ratio_hook) {
     const bool on = (opts.flags & RH_SINGLE_PASS) != 0 || env_long("RUHVRO_HIP_SINGLE_PASS", kSinglePassDefault, 0, 1) != 0;
     // (device-resident calls only: a host call is bound by the PCIe link, and its D2H copy would carry the capacity slack)
-    if (!on || range_of_host_call || (opts.flags & (RH_INTERNAL_TWO_PASS | RH_TWO_PASS)) || !sk || !sk->fused_fn || K <= 0 || K > 64 || n == 0 || two_sync ||
+    if (!on || range_of_host_call || (opts.flags & (RH_INTERNAL_TWO_PASS | RH_TWO_PASS)) || !sk || K <= 0 || K > 64 || n == 0 || two_sync ||
         ratio_hook >= 0)
       return false;
     if (n_entries > (1u << 16)) return false;
+    if (8ull * K * k > 4ull * K * nblocks) return false;      // the capacities travel in the workspace's blocksum area (below)
+    // the single-pass kernel is its own code object, compiled when a call first asks for it (in the background unless the
+    // caller insists on specialised kernels): until it is there the call takes the two-pass form
+    hipFunction_t fused_fn = sk->fused_fn.load(std::memory_order_acquire);
+    if (!fused_fn) {
+      if (sk->fused_dead) return false;
+      fused_fn = spec_kernel(s, device, compile_policy(opts.flags & 3, n), false, true).fused_fn.load(std::memory_order_acquire);
+      if (!fused_fn) return false;
+    }
     std::vector<double> per_row;
     {
       std::lock_guard<std::mutex> g(s->mu);
@@ -1090,7 +1147,6 @@ struct rh_decode_call {
     hcaps = Lease(pin_pool(), 8ull * K * k, device);
     std::memcpy(hcaps.ptr(), caps.data(), 8ull * K * k);
     uint64_t* d_caps = (uint64_t*)P.blocksum;
-    if (8ull * K * k > 4ull * K * nblocks) { single = false; fused = false; r.arena.release(); lookback.release(); hcaps.release(); return false; }
     HIPCHK(hipMemcpyAsync(d_caps, hcaps.ptr(), 8ull * K * k, hipMemcpyHostToDevice, stream));
     P.lookback = (unsigned long long*)lookback.ptr();
     P.caps = d_caps;
@@ -1105,7 +1161,7 @@ struct rh_decode_call {
       throw HipError("k_init launch failed");
     const uint64_t tiles_max = std::max<uint64_t>((r.sz + tile - 1) / tile, (r.rows_last + tile - 1) / tile);
     emit_lds = lds_bytes;
-    if (launch_module(sk->fused_fn, P, (uint32_t)(tiles_max * k), (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4)))
+    if (launch_module(fused_fn, P, (uint32_t)(tiles_max * k), (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4)))
       throw HipError("k_fused launch failed");
     basis = (double)payload + 64.0 * (double)n;
     void* hdev = nullptr;
@@ -1173,8 +1229,7 @@ struct rh_decode_call {
                                      (long)std::min<uint64_t>(1ull << 28, (1ull << 32) / std::max<uint32_t>(cs.max_row_bytes, 16)), 1, 1l << 28);
     const bool narrow_ok = std::max(r.sz, r.rows_last) < narrow_rows;
     if (mode != RH_KERNEL_GENERIC && n > 0 && narrow_ok) {
-      const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
-      const SpecKernel& k0 = spec_kernel(s, device, may_compile);
+      const SpecKernel& k0 = spec_kernel(s, device, compile_policy(mode, n));
       if (k0.ok) sk = &k0;
       else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
     }
@@ -2581,11 +2636,12 @@ void rh_schema_free(rh_schema* s) {
     (void)hipFree(kv.second.desc);
     (void)hipFree(kv.second.cnt_databuf);
   }
-  for (auto& kv : s->spec)
-    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
-  for (auto& kv : s->espec)
-    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
-  delete s;
+  for (auto* table : {&s->spec, &s->espec})
+    for (auto& kv : *table)
+      if (kv.second)
+        for (hipModule_t m : kv.second->mod)
+          if (m) (void)hipModuleUnload(m);
+  delete s;      // (compile jobs still running hold their own reference to `images`)
 }
 
 int rh_schema_export(const rh_schema* s, struct ArrowSchema* out) {
@@ -2639,18 +2695,33 @@ char* rh_schema_encode_kernel_source(const rh_schema* s) {
 int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
   if (!s) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
-    bool hit = false, ehit = false;
-    std::vector<char> image = rh::get_kernel_image(*s->cs, true, &hit);
-    if (image.empty()) throw std::runtime_error("kernel image empty");
-    if (s->cs->encode_unsupported.empty()) {
-      image = rh::get_kernel_image(*s->cs, true, &ehit, true);       // and the Arrow -> Avro pair
-      if (image.empty()) throw std::runtime_error("encode kernel image empty");
-    } else {
-      ehit = true;                                                   // a schema rh_encode does not take
+    // every kernel of the schema, each its own compile job, side by side (kernel_jobs.h); waits for all of them
+    const unsigned parts = rh::kDecodeParts | (s->cs->encode_unsupported.empty() ? rh::kEncodeParts : 0u);
+    rh::KernelImage im[rh::KP_COUNT];
+    const unsigned started = rh::kernel_images(s->images, *s->cs, parts, rh::CP_BLOCKING, im);
+    for (int p = 0; p < rh::KP_COUNT; p++) {
+      if (!(parts & (1u << p)) || im[p].state == rh::IMG_NONE) continue;
+      if (im[p].state != rh::IMG_READY) throw std::runtime_error(std::string(rh::kernel_part_entry(p)) + ": " + (im[p].why.empty() ? "kernel image missing" : im[p].why));
     }
-    if (cached) *cached = (hit && ehit) ? 1 : 0;
+    if (cached) *cached = started == 0 ? 1 : 0;      // nothing had to be compiled
     return RH_OK;
   });
+}
+
+int rh_schema_kernels_ready(const rh_schema* s, int encode, long timeout_ms, char** err) {
+  if (!s) return -1;
+  try {
+    const unsigned parts = encode ? rh::kEncodeParts : ((1u << rh::KP_SIZE) | (1u << rh::KP_EMIT));
+    rh::KernelImage im[rh::KP_COUNT];
+    rh::kernel_images(s->images, *s->cs, parts, rh::CP_CACHED_ONLY, im);      // (a first look at the disk cache; starts nothing)
+    std::string why;
+    const int rc = rh::kernel_images_wait(s->images, parts, timeout_ms, &why);
+    if (rc < 0 && err) *err = dup_msg(why);
+    return rc;
+  } catch (const std::exception& e) {
+    if (err) *err = dup_msg(e.what());
+    return -1;
+  }
 }
 
 uint32_t rh_device_result_chunks(const rh_device_result* r) { return r ? r->k : 0; }
@@ -3093,8 +3164,7 @@ int encode_impl(rh_schema* s, const ArrowArray* batch, const ArrowSchema* bschem
   const int mode = opts ? (opts->flags & 3) : RH_KERNEL_AUTO;
   const SpecKernel* sk = nullptr;
   if (mode != RH_KERNEL_GENERIC && n > 0) {
-    const bool may_compile = mode == RH_KERNEL_SPECIALIZED || n >= spec_min_records();
-    const SpecKernel& k0 = spec_kernel(s, device, may_compile, true);
+    const SpecKernel& k0 = spec_kernel(s, device, compile_policy(mode, n), true);
     if (k0.ok) sk = &k0;
     else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised encode kernel unavailable: " + k0.why);
   }

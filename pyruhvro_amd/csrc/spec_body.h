@@ -499,13 +499,18 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       // workgroup-local exclusive prefix.  Lane k sums counter k's totals of the wavefronts in front of this one (three
       // LDS reads at most); every lane then takes counter k's sum from lane k with v_readlane: 2 VALU per counter, not
       // the 5-6 of selecting and adding NW - 1 broadcast totals per counter in every lane
-      uint32_t prev = 0;
-      if (lane < (uint32_t)S::K) {
-        for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + lane] : 0u;
-      }
-      static_for<0, S::K>([&](auto ik) {
-        constexpr int k = decltype(ik)::value;
-        c.cnt[k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+      // (v_readlane selects among 64 lanes: schemas with more counters -- up to kMaxCounters = 96 -- take them 64 at a time)
+      static_for<0, (S::K + 63) / 64>([&](auto ig) {
+        constexpr int k0 = decltype(ig)::value * 64;
+        constexpr int kn = S::K - k0 < 64 ? S::K - k0 : 64;
+        uint32_t prev = 0;
+        if (lane < (uint32_t)kn) {
+          for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + k0 + lane] : 0u;
+        }
+        static_for<0, kn>([&](auto ik) {
+          constexpr int k = decltype(ik)::value;
+          c.cnt[k0 + k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+        });
       });
     }
   }
@@ -746,13 +751,18 @@ __device__ __forceinline__ void spec_fused(const KParams& P) {
       c.gb[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.gbx[k]);
     });
     if constexpr (NW > 1) {
-      uint32_t prev = 0;
-      if (lane < (uint32_t)S::K) {
-        for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + lane] : 0u;
-      }
-      static_for<0, S::K>([&](auto ik) {
-        constexpr int k = decltype(ik)::value;
-        c.cnt[k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+      // (v_readlane selects among 64 lanes: schemas with more counters -- up to kMaxCounters = 96 -- take them 64 at a time)
+      static_for<0, (S::K + 63) / 64>([&](auto ig) {
+        constexpr int k0 = decltype(ig)::value * 64;
+        constexpr int kn = S::K - k0 < 64 ? S::K - k0 : 64;
+        uint32_t prev = 0;
+        if (lane < (uint32_t)kn) {
+          for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + k0 + lane] : 0u;
+        }
+        static_for<0, kn>([&](auto ik) {
+          constexpr int k = decltype(ik)::value;
+          c.cnt[k0 + k] += (uint32_t)__builtin_amdgcn_readlane((int)prev, k);
+        });
       });
     }
   }

@@ -9,19 +9,23 @@ namespace rh {
 
 // Records (= threads) per workgroup of the specialised kernels: 256 unless RUHVRO_HIP_TILE says 64, 128, 512 or 1024.
 int spec_tile_records();
-// HIP source of the specialised k_size / k_emit pair for this schema.
-std::string generate_kernel_source(const CompiledSchema& cs);
+// The specialised kernels of a schema.  Each is its own hiprtc program (its own code object in the kernel cache), so that a
+// cache miss compiles them side by side (kernel_jobs.cpp) and the opt-in single-pass kernel is only built when asked for.
+enum KernelPart { KP_SIZE = 0, KP_EMIT = 1, KP_FUSED = 2, KP_ESIZE = 3, KP_EEMIT = 4, KP_COUNT = 5 };
+constexpr unsigned kDecodeParts = 7u, kEncodeParts = 24u;
+inline const char* kernel_part_entry(int part) {
+  static const char* const names[KP_COUNT] = {"rh_spec_size", "rh_spec_emit", "rh_spec_fused", "rh_espec_size", "rh_espec_emit"};
+  return names[part];
+}
+// HIP source of the specialised decode kernels (rh_spec_size / rh_spec_emit / rh_spec_fused) of this schema; `parts` = the
+// kernel entries to emit (bit KernelPart).  The default is the whole set: what rh_schema_kernel_source shows and what the
+// measurement stamps hash (rh_schema_kernel_key).
+std::string generate_kernel_source(const CompiledSchema& cs, unsigned parts = kDecodeParts);
 // HIP source of the specialised Arrow -> Avro pair (rh_espec_size / rh_espec_emit) for this schema.
-std::string generate_encode_source(const CompiledSchema& cs);
-// Content hash of (source + the device headers it includes): the on-disk cache key.
-std::string kernel_cache_key(const std::string& source, bool encode = false);
-// Directory of cached code objects: $RUHVRO_HIP_KERNEL_CACHE or <library dir>/_kcache.
-std::string kernel_cache_dir();
-// hiprtc: source -> gfx950 code object (works without a GPU).  Throws std::runtime_error.
-std::vector<char> compile_kernel(const std::string& source, std::string& log);
-// Cached code object, compiling (and storing) on a miss when allowed; empty if absent and !allow_compile.
-// `encode` selects the Arrow -> Avro kernels instead of the decode kernels.
-std::vector<char> get_kernel_image(const CompiledSchema& cs, bool allow_compile, bool* from_cache, bool encode = false);
+std::string generate_encode_source(const CompiledSchema& cs, unsigned parts = kEncodeParts);
+// Source of ONE part, or "" when the schema has no such kernel (rh_spec_fused needs K <= 64; the encode pair a schema
+// rh_encode takes).
+std::string generate_part_source(const CompiledSchema& cs, int part);
 
 // Host mirror of spec_body.h's spec_lds_fixed_words (LDS words in front of the window).
 inline uint32_t spec_lds_fixed_words_host(int K, int nnodes, int nw, int nbm, int ndense, int nb0) {

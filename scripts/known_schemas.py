@@ -22,7 +22,7 @@ def known_schemas() -> List[str]:
     try:
         import json
         import cases
-        for c in cases.wire_cases() + cases.nesting_cases() + cases.dense_list_cases() + cases.enum_form_cases():
+        for c in cases.wire_cases() + cases.nesting_cases() + cases.dense_list_cases() + cases.enum_form_cases() + cases.wide_counter_cases():
             out.append(c[1])
         for c in cases.error_cases():
             out.append(c[1])

@@ -303,6 +303,34 @@ def long_string_case(n=1500, seed=5):
     return s, _enc(s, vals)
 
 
+def wide_counter_cases():
+    """Schemas with MORE THAN 64 scanned counters (one per string column, one per child row domain; the engine's limit is
+    96, program.h kMaxCounters): the specialised emit kernel's workgroup prefix takes the counters from lanes with
+    v_readlane, which selects among 64 lanes only (counters 64.. got counter k - 64's prefix).  70 and 96
+    counters, every column with its own length pattern so that a swapped prefix cannot go unnoticed.
+    -> list of (name, schema_json, records)."""
+    out = []
+    for total in (70, 96):
+        nstr = total - 2                                   # + the array's row domain and its item bytes
+        fields = [{"name": f"s{i}", "type": "string" if i % 3 else ["null", "string"]} for i in range(nstr // 2)]
+        fields.append({"name": "tags", "type": {"type": "array", "items": "string"}})
+        fields += [{"name": f"s{i}", "type": "string"} for i in range(nstr // 2, nstr)]
+        sj = json.dumps({"type": "record", "name": f"Wide{total}", "fields": fields})
+        vals = []
+        for r in range(700):
+            v = {}
+            for i in range(nstr):
+                if i < nstr // 2 and i % 3 == 0 and (r + i) % 4 == 0:
+                    v[f"s{i}"] = None
+                else:
+                    # (short strings: 256 records of either schema still fit one LDS window, so the tiles take the staged walk)
+                    v[f"s{i}"] = chr(65 + i % 26) * ((r * (i + 1) + i) % (4 if total == 70 else 3)) + (f"<{r}>" if (r + i) % 23 == 0 else "")
+            v["tags"] = [f"t{r}.{j}" for j in range((r * 3) % 5)]
+            vals.append(v)
+        out.append((f"wide_{total}_counters", sj, _enc(sj, vals)))
+    return out
+
+
 def enum_form_cases():
     """Enums on both sides of the specialised kernels' symbols-as-immediates rule (specialize.cpp Spec::enum_sym: at most 16
     symbols of at most 8 bytes get their length from a select chain in the size pass; anything else reads the symbol

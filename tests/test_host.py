@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"libruhvro_hip.so does not export {n}"
-    assert cabi.lib().rh_abi_version() == 5
+    assert cabi.lib().rh_abi_version() == 6
 
 
 def test_clamp_chunks_matches_reference():   # deserialize.rs:53-55

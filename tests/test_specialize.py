@@ -29,16 +29,43 @@ def test_generated_source_follows_the_schema_program():
 
 def test_prebuild_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
     monkeypatch.setenv("RUHVRO_HIP_KERNEL_CACHE", str(tmp_path))
-    schema = SCHEMAS["t_enum"]
+    schema = SCHEMAS["t_enum"] + " "                 # (a schema handle of this test's own: handles remember their code objects)
     assert cabi.prebuild(schema) is False            # compiled now
     files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
-    assert len(files) == 2                           # the decode pair and the Arrow -> Avro pair
+    # every kernel is its own code object (compiled side by side by rh_kcompile helper processes, kernel_jobs.cpp):
+    # rh_spec_size / rh_spec_emit / rh_spec_fused and the Arrow -> Avro pair
+    assert len(files) == 5
+    assert sorted(os.listdir(tmp_path)) == sorted(files)      # no lock / source / log files left behind
     blobs = [open(os.path.join(tmp_path, f), "rb").read() for f in files]
     assert all(b[:4] == b"\x7fELF" and b"gfx950" in b for b in blobs)
-    assert sum(b"rh_spec_emit" in b for b in blobs) == 1 and sum(b"rh_espec_emit" in b for b in blobs) == 1
-    assert cabi.prebuild(schema) is True             # cache hit
-    assert cabi.prebuild(SCHEMAS["t_union"]) is False   # different schema -> different keys
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 4
+    for entry in (b"rh_spec_size", b"rh_spec_emit", b"rh_spec_fused", b"rh_espec_size", b"rh_espec_emit"):
+        assert sum(entry in b for b in blobs) == 1
+    assert cabi.prebuild(schema) is True             # nothing to compile
+    assert cabi.prebuild(SCHEMAS["t_enum"] + "  ") is True     # another handle of the same schema: disk cache hit
+    assert cabi.prebuild(SCHEMAS["t_union"] + " ") is False   # different schema -> different keys
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 10
+    assert cabi.kernels_ready(schema) and cabi.kernels_ready(schema, encode=True)
+
+
+def test_in_process_compile_when_the_helper_is_absent(tmp_path):
+    """Without rh_kcompile next to the library the jobs compile on threads of the process (RUHVRO_HIP_KCOMPILE=0 forces it)."""
+    code = ("import os, sys; from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS\n"
+            "assert cabi.prebuild(SCHEMAS['t_enum']) is False\n"
+            "assert len([f for f in os.listdir(os.environ['RUHVRO_HIP_KERNEL_CACHE']) if f.endswith('.hsaco')]) == 5\n")
+    env = dict(os.environ, RUHVRO_HIP_KERNEL_CACHE=str(tmp_path), RUHVRO_HIP_KCOMPILE="0")
+    subprocess.check_call([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_compile_failure_is_reported_not_hung(tmp_path):
+    """A helper that cannot compile (here: one that always fails) turns into an error message, for prebuild and kernels_ready."""
+    fake = tmp_path / "fake_kcompile"
+    fake.write_text("#!/bin/sh\necho 'no compiler today' > \"$3\"\nexit 1\n")
+    fake.chmod(0o755)
+    code = ("from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS\n"
+            "try:\n    cabi.prebuild(SCHEMAS['t_enum']); raise SystemExit('no error')\n"
+            "except RuntimeError as e:\n    assert 'no compiler today' in str(e), str(e)\n")
+    env = dict(os.environ, RUHVRO_HIP_KERNEL_CACHE=str(tmp_path / "kc"), RUHVRO_HIP_KCOMPILE=str(fake))
+    subprocess.check_call([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def test_encode_source_issues_a_row_domains_loads_before_its_first_write():
@@ -105,7 +132,8 @@ def test_staged_kernel_variants_compile_and_are_keyed_apart(tmp_path, monkeypatc
     for name in STAGED_VARIANTS.split(","):
         assert f"#define RH_V_{name} 1" in var_src
     assert var_src.replace("".join(f"#define RH_V_{n} 1\n" for n in STAGED_VARIANTS.split(",")), "") == base_src
-    assert cabi.prebuild(schema) is False                      # compiled now, under other keys
+    # (a schema handle remembers its code objects; the variant set is read per generated source -> a fresh handle sees it)
+    assert cabi.prebuild(schema + " ") is False                # compiled now, under other keys
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2 * n_default
     monkeypatch.setenv("RUHVRO_HIP_VARIANT", "not a name,lower,OK_1")
     assert "RH_V_OK_1" in cabi.kernel_source(schema) and "lower" not in cabi.kernel_source(schema)
