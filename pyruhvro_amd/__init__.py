@@ -267,9 +267,24 @@ def device_count() -> int:
     return _require_native().device_count()
 
 
+def kernels_ready(schema: str, encode: bool = False, timeout_ms: int = 0) -> bool:
+    """Extension.  A schema this process has not met is decoded by the generic kernels at once while the kernels specialised
+    to it compile in the background (the reference's cost of a new schema is a JSON parse, ``src/lib.rs:39-54``; a hiprtc
+    compile is seconds).  True when they are there -- the next call runs on them; waits up to ``timeout_ms`` for running
+    compile jobs.  Raises ``RuntimeError`` if the compile failed (calls keep working on the generic kernels)."""
+    return bool(_require_native().kernels_ready(_get_schema(schema).capsule, bool(encode), int(timeout_ms)))
+
+
+def prebuild(schema: str) -> bool:
+    """Extension.  Compile this schema's specialised kernels now (all of them, side by side) and wait: for services that
+    want their first batch at full speed.  The code objects land in the kernel cache (``RUHVRO_HIP_KERNEL_CACHE`` or
+    ``pyruhvro_amd/_kcache``), where later processes find them.  True when nothing had to be compiled."""
+    return bool(_require_native().prebuild(_get_schema(schema).capsule))
+
+
 __all__ = [
     "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
     "serialize_record_batch_with_stats",
     "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count", "set_kernel_mode",
-    "deserialize_binary_array", "set_devices",
+    "deserialize_binary_array", "set_devices", "kernels_ready", "prebuild",
 ]

@@ -451,6 +451,38 @@ PyObject* py_release_array(PyObject*, PyObject* args) {
 
 PyObject* py_device_count(PyObject*, PyObject*) { return PyLong_FromLong(rh_device_count()); }
 
+// kernels_ready(capsule, encode=False, timeout_ms=0) -> bool: rh_schema_kernels_ready (the GIL is released while it waits)
+PyObject* py_kernels_ready(PyObject*, PyObject* args) {
+  PyObject* cap;
+  int encode = 0;
+  long timeout_ms = 0;
+  if (!PyArg_ParseTuple(args, "O|pl", &cap, &encode, &timeout_ms)) return nullptr;
+  rh_schema* s = get_schema(cap);
+  if (!s) return nullptr;
+  char* err = nullptr;
+  int rc;
+  Py_BEGIN_ALLOW_THREADS
+  rc = rh_schema_kernels_ready(s, encode, timeout_ms, &err);
+  Py_END_ALLOW_THREADS
+  if (rc < 0) return raise_from(RH_ERR_RUNTIME, err);
+  return PyBool_FromLong(rc == 1);
+}
+
+// prebuild(capsule) -> bool (True: nothing had to be compiled): rh_schema_prebuild, GIL released
+PyObject* py_prebuild(PyObject*, PyObject* args) {
+  PyObject* cap;
+  if (!PyArg_ParseTuple(args, "O", &cap)) return nullptr;
+  rh_schema* s = get_schema(cap);
+  if (!s) return nullptr;
+  char* err = nullptr;
+  int rc, cached = 0;
+  Py_BEGIN_ALLOW_THREADS
+  rc = rh_schema_prebuild(s, &cached, &err);
+  Py_END_ALLOW_THREADS
+  if (rc != RH_OK) return raise_from(rc, err);
+  return PyBool_FromLong(cached);
+}
+
 // last_decode_profile() -> dict: phase milliseconds of this thread's most recent decode() (up to the point where the result
 // list is built), incl. the time the call held the GIL
 PyObject* py_last_decode_profile(PyObject*, PyObject*) {
@@ -468,6 +500,8 @@ PyMethodDef methods[] = {
     {"release_array", py_release_array, METH_VARARGS, "release + free an ArrowArray shell"},
     {"free_struct", py_free_struct, METH_VARARGS, "free a struct shell whose content was moved"},
     {"device_count", py_device_count, METH_NOARGS, "number of HIP devices"},
+    {"kernels_ready", py_kernels_ready, METH_VARARGS, "kernels_ready(capsule, encode=False, timeout_ms=0) -> bool"},
+    {"prebuild", py_prebuild, METH_VARARGS, "prebuild(capsule) -> bool"},
     {"last_decode_profile", py_last_decode_profile, METH_NOARGS, "phase milliseconds of this thread's most recent decode()"},
     {nullptr, nullptr, 0, nullptr}};
 

@@ -85,7 +85,7 @@ def test_python_surface_on_a_cold_schema(tmp_path, monkeypatch):
     assert st["specialized"] == 0 and ms < 500
     for g, e in zip(got, c_walker.decode_threaded(recs, SCHEMAS["cfg3"], 4)):
         assert_batches_identical(g, e)
-    assert cabi.kernels_ready(schema, timeout_ms=240_000)
+    assert P.kernels_ready(schema, timeout_ms=240_000)
     got, st = P.deserialize_array_threaded_with_stats(recs, schema, 4)
     assert st["specialized"] == 1
     for g, e in zip(got, c_walker.decode_threaded(recs, SCHEMAS["cfg3"], 4)):
