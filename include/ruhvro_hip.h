@@ -265,8 +265,15 @@ uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint32_t shards,
                          uint32_t threads_per_shard, int pinned, uint32_t reps, double* best_ms);
 
+/* Test hook, not part of the drop-in surface: exercises the host thread pool behind the gather of pipelined calls (its
+ * lock-free phase hand-over); 0 = every task of every phase ran exactly once.  tests/test_host.py. */
+uint32_t rh_selftest_pool(uint32_t workers, uint32_t phases, uint32_t max_tasks);
+
 void rh_free_string(char* s);
 int rh_abi_version(void);
+/* CPUs the process may use: hardware threads cut down to its affinity mask and its cgroup CPU quota -- what the engine
+ * sizes its host thread pools by, and what a binding should size its own by (the CPython boundary's extractor threads do). */
+uint32_t rh_effective_cpus(void);
 /* Number of visible HIP devices (0 when no GPU / driver); never throws. */
 int rh_device_count(void);
 /* The calling thread's current HIP device (what rh_opts.device = -1 resolves to on this thread), or -1 when there is

@@ -74,6 +74,7 @@ int with_stats_line(const char* entry, const rh_opts* opts, rh_stats* stats, F&&
 extern "C" {
 
 int rh_abi_version(void) { return RH_ABI_VERSION; }
+uint32_t rh_effective_cpus(void) { return effective_cpus(); }
 
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n) {
   for (uint32_t i = 0; i < n && i < (uint32_t)RH_CTR_COUNT; i++) out[i] = g_counters[i].load(std::memory_order_relaxed);

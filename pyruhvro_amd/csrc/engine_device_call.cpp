@@ -71,6 +71,27 @@ struct rh_decode_call {
     opts.devices = nullptr; opts.n_devices = 0; opts.device_stats = nullptr; opts.ready = nullptr; opts.gathered = nullptr;   // (not used below; never dangling)
   }
 
+  // Where the call's Arrow buffers go: HBM, or -- host calls, RH_INTERNAL_HOST_ARENA -- a pooled block of PINNED HOST memory that
+  // the emit kernel fills through the PCIe link and that is then lent to the result (engine_export.cpp to_host_impl): no D2H
+  // copy, no host wait between kernels and copy, and the copy engine is left to the H2D copies of the next chunk group (the two
+  // directions on SDMA shared ~56 GB/s between them: a 1M-record call's D2H copies ran at 32 GB/s beside its H2D copies,
+  // profiles/r05h_*).  The CUs' stores reach the full rate of the link: 53 GB/s, what a D2H copy of the same bytes reaches
+  // (profiles/r05i_host_arena.txt).  Only with a block that sits idle in the pool -- allocating one costs 0.2 ms per MB, so the
+  // pool is refilled in the background (Pool::prefetch) -- and not for schemas whose child-domain bitmaps are built with
+  // atomics on the arena.  RUHVRO_HIP_HOST_ARENA=0 turns it off (A/B).
+  Lease arena_lease(uint64_t bytes) {
+    r.arena_host = false;
+    if ((opts.flags & RH_INTERNAL_HOST_ARENA) && !child_bitmaps && env_long("RUHVRO_HIP_HOST_ARENA", 1, 0, 1) != 0) {
+      Block b = pin_pool().try_get(bytes, device);
+      if (b.p) {
+        r.arena_host = true;
+        return Lease(pin_pool(), b);
+      }
+      pin_pool().prefetch(bytes + bytes / 16, device, pinned_budget_left());
+    }
+    return Lease(dev_pool(), bytes, device);
+  }
+
   void check_bad(const uint8_t* h) {
     unsigned long long fb = *(const unsigned long long*)h;
     if (!fb) return;
@@ -116,7 +137,7 @@ struct rh_decode_call {
     ctrl->b.clean = false;
     published = false;       // (the raw device layout is copied back below)
     layout_host();
-    r.arena = Lease(dev_pool(), r.arena_bytes, device);
+    r.arena = arena_lease(r.arena_bytes);
     Lease htab(pin_pool(), tab_bytes, device);
     void** hptr = (void**)htab.ptr();
     uint64_t* hsz = (uint64_t*)(htab.ptr() + (uint64_t)std::max(nbuf, 1) * k * 8);
@@ -407,7 +428,7 @@ struct rh_decode_call {
     if (fused) {
       count(RH_CTR_FUSED_CALLS);
       const uint64_t capacity = align_up((uint64_t)(ratio * basis * 1.125) + n_entries * kAlign + (1u << 20), kAlign);
-      r.arena = Lease(dev_pool(), capacity, device);
+      r.arena = arena_lease(capacity);
       rh::LParams LP;
       std::memset(&LP, 0, sizeof LP);
       LP.totals = P.totals; LP.desc = dp->desc; LP.sz = r.sz; LP.rows_last = r.rows_last; LP.n = n; LP.k = k;
@@ -776,6 +797,7 @@ void settle(rh_device_result* r) {
     }
     call.reset();                                  // (its reference to *r ends here)
     r->arena = std::move(r2->arena);
+    r->arena_host = r2->arena_host;
     r->arena_bytes = r2->arena_bytes;
     r->buf_off = std::move(r2->buf_off); r->buf_size = std::move(r2->buf_size); r->dom_rows = std::move(r2->dom_rows);
     r->data_bytes = std::move(r2->data_bytes); r->nullcount = std::move(r2->nullcount); r->layout_bytes = std::move(r2->layout_bytes);

@@ -186,21 +186,20 @@ void export_field(const rh::ArrowField& f, ArrowSchema* out) {
 }
 
 
-// Device range -> freshly owned host memory.  Large results land in pooled PINNED memory (the copy then runs at PCIe
-// speed, 57 GB/s measured) as long as a cached block is free or the pinned memory lent to still-live results stays
-// under a bound; a caller that keeps many results alive gets pageable memory instead of a fresh 0.15 ms/MB
-// hipHostMalloc per call.
+// Device range -> freshly owned host memory.  Large results land in pooled PINNED memory when a block is idle in the pool (the
+// copy then runs at PCIe speed, 57 GB/s measured), else in pageable memory (15-22 GB/s) while the pool is refilled in the
+// background: hipHostMalloc costs 0.2 ms per MB (tools/d2hcost.hip) -- on the call's own path that was 32 ms for the results
+// of a 1M-record call whose predecessor's batches were still alive, twice the call itself.
 Slab* slab_from_device(const uint8_t* dptr, uint64_t bytes, int device, hipStream_t stream) {
   Slab* slab = new Slab();
   try {
     if (bytes >= (1ull << 20)) {
       slab->pinned = pin_pool().try_get(bytes, device);
-      const uint64_t bound = std::max<uint64_t>(4ull << 30, 2 * bytes);
-      if (!slab->pinned.p && Slab::pinned_result_bytes().load() + bytes <= bound)
-        slab->pinned = pin_pool().get(bytes, device);
       if (slab->pinned.p) {
         Slab::pinned_result_bytes().fetch_add(slab->pinned.size);
         slab->base = slab->pinned.p;
+      } else {
+        pin_pool().prefetch(bytes + bytes / 16, device, pinned_budget_left());
       }
     }
     if (!slab->base && posix_memalign(&slab->base, 64, std::max<uint64_t>(bytes, 64)) != 0) throw std::bad_alloc();
@@ -234,7 +233,18 @@ int to_host_impl(rh_device_result* r, ArrowArray* out_chunks, hipStream_t stream
     return 0;
   }
   r->tables();
-  Slab* slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
+  Slab* slab = nullptr;
+  if (r->arena_host) {          // the emit kernel wrote into pinned host memory: the result takes the block over as it is
+    slab = new Slab();
+    slab->pinned = r->arena.b;
+    slab->base = r->arena.b.p;
+    Slab::pinned_result_bytes().fetch_add(slab->pinned.size);
+    r->arena.pool = nullptr;
+    r->arena.b = Block();
+    r->arena_host = false;
+  } else {
+    slab = slab_from_device(r->arena.ptr(), r->arena_bytes, r->device, stream);
+  }
   slab->refs.store(1);   // guard while building
   uint32_t built = 0;
   try {

@@ -3,6 +3,10 @@
 // (ruhvro/src/deserialize.rs:76-121: pack, slice, one task per chunk, ordered join).
 #include "engine_internal.h"
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 namespace rhe {
 
 void require_device() {
@@ -51,55 +55,113 @@ void run_threads(unsigned nt, const std::function<void(unsigned)>& f) {
   for (auto& x : th) x.join();
 }
 
-// A pool of host threads that lives for one call: parallel_for hands out task indices to the workers and returns when
-// all are done.  The gather of a pipelined call runs shard after shard on it (creating 2 x 32 threads per shard instead
-// costs more than the gather itself).
+// A pool of host threads: parallel_for hands out task indices to the workers (and to the caller) and returns when all are
+// done.  The gather of a pipelined call runs group after group on it, two short phases per group, so what a phase costs
+// beyond its work decides the call: with a mutex + condition variable per phase a 16 MB group took 0.6 ms to gather on 32
+// threads (RUHVRO_HIP_TIMELINE, profiles/r05c_*: the gather chain, not the PCIe link, bounded a 1M-record call).  Here the
+// hand-over is lock-free -- one 64-bit ticket word carries the phase's generation in its high half and the next task index
+// in its low half; a claim is one fetch_add -- and workers that run out of tasks poll the ticket for ~50 us (the second
+// phase of a group follows the first at once) before they sleep on a futex, from which all of them wake side by side.
 class CallPool {
  public:
   explicit CallPool(unsigned workers) {
     for (unsigned i = 0; i < workers; i++) th_.emplace_back([this] { work(); });
   }
   ~CallPool() {
-    { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
-    cv_start_.notify_all();
+    stop_.store(true, std::memory_order_seq_cst);
+    gen32_.fetch_add(0x80000000u, std::memory_order_seq_cst);      // (any change of the word ends a futex wait)
+    futex_wake_all();
     for (auto& t : th_) t.join();
   }
   unsigned workers() const { return (unsigned)th_.size(); }
   void parallel_for(unsigned ntasks, const std::function<void(unsigned)>& f) {     // one caller at a time
     if (ntasks == 0) return;
-    std::unique_lock<std::mutex> l(mu_);
-    fn_ = &f; ntasks_ = ntasks; next_ = 0; left_ = ntasks; gen_++;
-    cv_start_.notify_all();
-    cv_done_.wait(l, [&] { return left_ == 0; });
-    fn_ = nullptr;
+    const uint64_t g = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
+    Slot& sl = slot_[g & 1];
+    sl.fn.store(&f, std::memory_order_relaxed);
+    sl.ntasks.store(ntasks, std::memory_order_relaxed);
+    left_.store(ntasks, std::memory_order_relaxed);
+    ticket_.store(g << 32, std::memory_order_seq_cst);
+    gen32_.store((uint32_t)g, std::memory_order_seq_cst);
+    if (sleepers_.load(std::memory_order_seq_cst) > 0) futex_wake_all();
+    run_tasks();                                     // the caller takes tasks too
+    for (unsigned spins = 0; left_.load(std::memory_order_acquire) != 0; spins++) {
+      if (spins < 4096) cpu_relax();
+      else std::this_thread::yield();
+    }
   }
 
  private:
-  void work() {
-    uint64_t seen = 0;
-    std::unique_lock<std::mutex> l(mu_);
+  struct Slot { std::atomic<const std::function<void(unsigned)>*> fn{nullptr}; std::atomic<unsigned> ntasks{0}; };
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  // Claims tasks of the current phase.  A claim is interpreted by the generation bits IT returned, so a thread that is late
+  // by a phase takes a task of the phase it finds, never one of a phase that is over.
+  void run_tasks() {
     for (;;) {
-      cv_start_.wait(l, [&] { return stop_ || (gen_ != seen && next_ < ntasks_); });
-      if (stop_) return;
-      seen = gen_;
-      while (fn_ && next_ < ntasks_) {
-        const unsigned t = next_++;
-        const std::function<void(unsigned)>* f = fn_;
-        l.unlock();
-        (*f)(t);
-        l.lock();
-        if (--left_ == 0) cv_done_.notify_all();
-        if (gen_ != seen) break;          // (cannot happen before left_ == 0; kept for clarity)
-      }
+      const uint64_t t = ticket_.fetch_add(1, std::memory_order_acq_rel);
+      const uint64_t tg = t >> 32;
+      const unsigned idx = (unsigned)(t & 0xFFFFFFFFu);
+      if (tg == 0) return;                                 // (no phase yet)
+      const Slot& sl = slot_[tg & 1];                      // (rewritten only by generation tg + 2: ruled out below)
+      const unsigned ntasks = sl.ntasks.load(std::memory_order_relaxed);
+      const std::function<void(unsigned)>* fn = sl.fn.load(std::memory_order_relaxed);
+      // phase tg ended while this thread looked: an unexecuted task keeps its phase open, so idx was beyond its tasks
+      if ((ticket_.load(std::memory_order_acquire) >> 32) != tg) continue;
+      if (idx >= ntasks) return;
+      (*fn)(idx);
+      left_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
+  void work() {
+    uint64_t seen = 0;
+    for (;;) {
+      const uint64_t g = ticket_.load(std::memory_order_acquire) >> 32;
+      if (g != seen) {
+        seen = g;
+        run_tasks();
+        continue;
+      }
+      // nothing new: poll for ~50 us (the next phase of the same group follows at once), then sleep on the generation word.
+      // (Polling through the gaps BETWEEN groups was measured and thrown out: 32 spinning threads slowed the caller's own
+      //  extraction threads on the GPU box -- a 1M-record call went from 6.7 to 9.2 ms, profiles/r05d_*.)
+      const auto t0 = std::chrono::steady_clock::now();
+      bool got = false;
+      for (unsigned spins = 0;; spins++) {
+        if (stop_.load(std::memory_order_relaxed)) return;
+        if ((ticket_.load(std::memory_order_acquire) >> 32) != seen) { got = true; break; }
+        cpu_relax();
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+      }
+      if (got) continue;
+      sleepers_.fetch_add(1, std::memory_order_seq_cst);
+      const uint32_t word = gen32_.load(std::memory_order_seq_cst);
+      if (word == (uint32_t)seen && !stop_.load(std::memory_order_seq_cst)) futex_wait(word);      // (returns at once if the word moved on)
+      sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+      if (stop_.load(std::memory_order_relaxed)) return;
+    }
+  }
+  // Sleep / wake on gen32_ without a mutex: the woken workers do not queue up behind one another to re-acquire a lock
+  // (condition_variable wake-ups of 32 waiters are serialised by the mutex they all return through).
+  void futex_wait(uint32_t expected) {
+    ::syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen32_), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+  }
+  void futex_wake_all() {
+    ::syscall(SYS_futex, reinterpret_cast<uint32_t*>(&gen32_), FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
+  }
   std::vector<std::thread> th_;
-  std::mutex mu_;
-  std::condition_variable cv_start_, cv_done_;
-  const std::function<void(unsigned)>* fn_ = nullptr;
-  unsigned ntasks_ = 0, next_ = 0, left_ = 0;
-  uint64_t gen_ = 0;
-  bool stop_ = false;
+  std::atomic<uint64_t> ticket_{0};
+  Slot slot_[2];
+  std::atomic<unsigned> left_{0};
+  std::atomic<unsigned> sleepers_{0};
+  std::atomic<bool> stop_{false};
+  std::atomic<uint32_t> gen32_{0};        // low half of the generation: the futex word
+  static_assert(sizeof(std::atomic<uint32_t>) == 4, "futex word");
 };
 
 // The gather pool and the shard streams of a pipelined host call are KEPT between calls: starting 32 threads while the caller's
@@ -280,7 +342,9 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   const uint64_t n = r1 - r0;
   rh_opts o = default_opts();
   o.device = device;
-  o.flags = opts ? (opts->flags & 3) : 0;      // kernel form only: the host paths settle every device call themselves
+  // kernel form only (the host paths settle every device call themselves) + the results may be written straight into pinned
+  // host memory (rh_decode_call::arena_lease)
+  o.flags = (opts ? (opts->flags & 3) : 0) | RH_INTERNAL_HOST_ARENA;
   o.stream = (void*)stream;
   float h2d = 0.f, pack_ms = 0.f;
   Lease din, pin;
@@ -362,7 +426,12 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   pin.release();            // the staging copy is done (decode_device_impl synchronised the stream)
   Timeline::mark(ticket, "kernels end");
   float d2h = 0.f;
-  {
+  if (r->arena_host) {             // nothing to copy: the result's buffers are in host memory already
+    Timer td;
+    to_host_impl(r.get(), out_chunks, stream);
+    d2h = td.ms();
+    Timeline::mark(ticket, "adopted");
+  } else {
     TurnstilePass pass(d2h_gate, ticket);
     Timeline::mark(ticket, "d2h begin");
     Range rd("ruhvro_hip:d2h+export");
@@ -507,7 +576,10 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
   // Record slices are gathered shard after shard by ONE pool of host threads, so the first shard is on the wire after
   // 1/ns of the gather time (side by side every shard would finish its gather at about the same, late, moment); each
   // shard's own thread waits for its block and takes it through H2D -> kernels -> D2H.
-  const unsigned pack_threads = std::max(1u, std::min(hw, 32u));
+  // (sized by the hardware threads, not by effective_cpus(): a cgroup quota bounds CPU TIME per period, not how many cores a
+  //  short burst may use -- the gather of a group is such a burst, and on the GPU box (256 threads, quota 16) 32 gather threads
+  //  beat 12: record_slices 40.6 vs 45.7 ms per 10M records, profiles/r05g_*.  RUHVRO_HIP_GATHER_THREADS: A/B knob.)
+  const unsigned pack_threads = (unsigned)env_long("RUHVRO_HIP_GATHER_THREADS", (long)std::max(1u, std::min(std::max(1u, std::thread::hardware_concurrency()), 32u)), 1, 256);
   struct Ready {
     std::mutex mu;
     std::condition_variable cv;
@@ -633,3 +705,30 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
 
 
 }  // namespace rhe
+
+// Test hook (include/ruhvro_hip.h): `phases` parallel_for phases of 1..max_tasks tasks on a CallPool of `workers` threads,
+// with pauses between some of them so that workers go through poll -> sleep -> wake; every task index of every phase must
+// run exactly once.  0 = ok, else the 1-based phase that went wrong.
+extern "C" uint32_t rh_selftest_pool(uint32_t workers, uint32_t phases, uint32_t max_tasks) {
+  using namespace rhe;
+  CallPool pool(std::max(1u, workers));
+  std::vector<std::atomic<uint32_t>> hits(std::max(1u, max_tasks));
+  uint64_t x = 88172645463325252ull;
+  for (uint32_t ph = 1; ph <= phases; ph++) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const unsigned nt = 1 + (unsigned)(x % std::max(1u, max_tasks));
+    for (auto& h : hits) h.store(0, std::memory_order_relaxed);
+    std::atomic<uint64_t> sum{0};
+    pool.parallel_for(nt, [&](unsigned t) {
+      hits[t].fetch_add(1, std::memory_order_relaxed);
+      sum.fetch_add(t + 1, std::memory_order_relaxed);
+    });
+    for (unsigned t = 0; t < nt; t++)
+      if (hits[t].load(std::memory_order_relaxed) != 1) return ph;
+    for (unsigned t = nt; t < max_tasks; t++)
+      if (hits[t].load(std::memory_order_relaxed) != 0) return ph;
+    if (sum.load() != (uint64_t)nt * (nt + 1) / 2) return ph;
+    if ((x >> 20) % 64 == 0) std::this_thread::sleep_for(std::chrono::microseconds(1500));     // let the workers fall asleep
+  }
+  return 0;
+}

@@ -89,6 +89,20 @@ inline void count(int which) { g_counters[which].fetch_add(1, std::memory_order_
   } while (0)
 
 char* dup_msg(const std::string& s);
+inline long env_long_early(const char* name, long dflt, long lo, long hi) {
+  const char* e = std::getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = nullptr;
+  const long v = std::strtol(e, &end, 10);
+  return (end && *end == 0 && v >= lo && v <= hi) ? v : dflt;
+}
+
+// CPUs this process may use over time: hardware threads, cut down to its affinity mask and to its cgroup CPU quota
+// (cpu.max / cfs_quota_us).  The GPU boxes report 256 hardware threads under a quota of 16 CPUs.  A quota bounds CPU TIME
+// per period, not the width of a short burst: this sizes what runs for SECONDS (the kernel compile jobs), and is why
+// idle threads here sleep instead of polling; the gather pool's bursts are sized by the hardware threads.
+// RUHVRO_HIP_CPUS overrides.
+unsigned effective_cpus();
 
 constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -175,6 +189,11 @@ class Pool {
     }
     trim(max_cached_);
   }
+  // Pinned pool only: make sure a block of this size class is (or soon will be) cached -- allocated by a background thread,
+  // because hipHostMalloc costs 0.2 ms per MB (tools/d2hcost.hip: 32 ms for a 1M-record call's results), never on a call's
+  // own path.  No-op when a suitable block is cached, when `budget_left` cannot take it, or when enough requests are queued.
+  void prefetch(uint64_t size, int device, uint64_t budget_left);
+  uint64_t cached_bytes() { std::lock_guard<std::mutex> g(mu_); return cached_; }
   void trim(uint64_t keep) {
     std::vector<Block> drop;
     {
@@ -210,6 +229,7 @@ struct Lease {   // RAII pool block
   Block b;
   Lease() = default;
   Lease(Pool& p, uint64_t size, int device) : pool(&p), b(p.get(size, device)) {}
+  Lease(Pool& p, Block taken) : pool(&p), b(taken) {}       // a block the caller took from `p` itself (Pool::try_get)
   Lease(const Lease&) = delete;
   Lease& operator=(const Lease&) = delete;
   Lease(Lease&& o) noexcept : pool(o.pool), b(o.b) { o.pool = nullptr; o.b = Block(); }
@@ -427,6 +447,7 @@ struct rh_device_result {
   uint64_t n = 0, sz = 0, rows_last = 0;
   uint32_t k = 1;
   rhe::Lease arena;                         // all Arrow buffers of all chunks
+  bool arena_host = false;             // the arena is pinned HOST memory the emit kernel wrote through the PCIe link (host calls): no D2H copy
   uint64_t arena_bytes = 0;
   std::vector<uint64_t> buf_off;       // [nbuf][k] offset into arena
   std::vector<uint64_t> buf_size;      // [nbuf][k] allocated bytes
@@ -495,6 +516,14 @@ struct Slab {   // host copy of the arena, shared by the k chunk arrays (freed w
   }
 };
 
+// Pinned host memory the engine may still lend to results: RUHVRO_HIP_PINNED_RESULT_MB (default 4096) less what live results
+// hold -- what Pool::prefetch is allowed to add.  (Idle blocks are bounded separately, by the pool's own cache limit.)
+inline uint64_t pinned_budget_left() {
+  static const uint64_t bound = (uint64_t)env_long_early("RUHVRO_HIP_PINNED_RESULT_MB", 4096, 0, 1 << 20) << 20;
+  const uint64_t used = Slab::pinned_result_bytes().load();
+  return used >= bound ? 0 : bound - used;
+}
+
 void export_chunk(const rh_device_result& r, uint32_t c, const uint8_t* base, Slab* slab, ArrowArray* out);
 void export_field(const rh::ArrowField& f, ArrowSchema* out);
 // Device range -> freshly owned host memory (pooled pinned memory for large results)
@@ -508,6 +537,7 @@ void settle(rh_device_result* r);
 // ---------------------------------------------------------------------------
 // integer knob from the environment, read at every use (tests change them inside one process); out of range = default
 constexpr long kSinglePassDefault = 0;           // RUHVRO_HIP_SINGLE_PASS: 1 = every qualifying call prefers the single-pass form (else RH_SINGLE_PASS per call)
+constexpr int RH_INTERNAL_HOST_ARENA = 0x200;    // rh_opts.flags, engine-internal (host calls): write the Arrow buffers straight into pinned host memory if a pooled block is free
 constexpr int RH_INTERNAL_TWO_PASS = 0x100;      // rh_opts.flags, engine-internal: this call must take the two-pass path
 constexpr long kInternalStreamsDefault = 1;      // RUHVRO_HIP_INTERNAL_STREAMS (decode_device_split)
 constexpr long kSplitMinDefault = 1000000;       // RUHVRO_HIP_SPLIT_MIN: records below which a call is never split

@@ -50,13 +50,17 @@ Registry& registry() {
   return *r;
 }
 
+// (the engine's effective_cpus() lives in engine_pools.cpp; this file is also part of nothing else, so it asks the C ABI)
+extern "C" uint32_t rh_effective_cpus(void);
+unsigned effective_cpus_for_jobs() { return rh_effective_cpus(); }
+
 unsigned max_jobs() {
   static const unsigned v = [] {
     if (const char* e = std::getenv("RUHVRO_HIP_COMPILE_JOBS")) {
       const long n = std::atol(e);
       if (n >= 1 && n <= 64) return (unsigned)n;
     }
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = effective_cpus_for_jobs();
     return std::max(1u, std::min(8u, hw ? hw / 2 : 2u));
   }();
   return v;

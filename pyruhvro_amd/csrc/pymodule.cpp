@@ -98,6 +98,64 @@ PyObject* stats_dict(const rh_stats& st) {
                        "total_ms", st.total_ms, "specialized", st.specialized, "lds_bytes", st.lds_bytes);
 }
 
+// A buffer of n 8-byte words from a cache of at most four idle ones (taken and returned with the GIL held, so no lock);
+// blocks beyond PYRUHVRO_SCRATCH_MAX_MB (default 512) are not kept.
+class Scratch {
+ public:
+  explicit Scratch(size_t words) : words_(words) {
+#ifdef Py_GIL_DISABLED
+    cap_ = words; p_ = std::malloc(cap_ * 8); return;      // free-threaded CPython: no GIL guards the cache, so there is none
+#endif
+    auto& idle = cache();
+    size_t best = idle.size();
+    for (size_t i = 0; i < idle.size(); i++)
+      if (idle[i].second >= words && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+    if (best < idle.size()) {
+      p_ = idle[best].first; cap_ = idle[best].second;
+      idle.erase(idle.begin() + (long)best);
+    } else {
+      cap_ = words;
+      p_ = std::malloc(cap_ * 8);
+    }
+  }
+  bool ok() const { return p_ != nullptr; }
+  ~Scratch() {
+    static const size_t max_words = [] {
+      const char* e = std::getenv("PYRUHVRO_SCRATCH_MAX_MB");
+      return (size_t)(e && *e ? std::atol(e) : 512l) * (1u << 20) / 8;
+    }();
+#ifdef Py_GIL_DISABLED
+    std::free(p_); return;
+#endif
+    auto& idle = cache();
+    if (p_ && cap_ <= max_words) {
+      if (idle.size() >= 4) {                 // full: the smallest block makes room (a process that went from small calls to
+        size_t small = 0;                     // large ones must end up caching the large blocks -- they are the expensive ones)
+        for (size_t i = 1; i < idle.size(); i++)
+          if (idle[i].second < idle[small].second) small = i;
+        if (idle[small].second >= cap_) { std::free(p_); return; }
+        std::free(idle[small].first);
+        idle.erase(idle.begin() + (long)small);
+      }
+      idle.emplace_back(p_, cap_);
+    } else {
+      std::free(p_);
+    }
+  }
+  Scratch(const Scratch&) = delete;
+  Scratch& operator=(const Scratch&) = delete;
+  template <typename T> T* as() const { static_assert(sizeof(T) == 8, "8-byte words"); return (T*)p_; }
+  template <typename T> T& at(size_t i) const { return ((T*)p_)[i]; }
+
+ private:
+  static std::vector<std::pair<void*, size_t>>& cache() {
+    static auto* v = new std::vector<std::pair<void*, size_t>>();
+    return *v;
+  }
+  void* p_ = nullptr;
+  size_t words_ = 0, cap_ = 0;
+};
+
 // Phase split of the calling thread's most recent decode() (last_decode_profile(); PYRUHVRO_PYPROF=1 prints the same line):
 // milliseconds of set-up, of the list extraction, of the rest of the call, and of the call's time with the GIL held.
 struct DecodeProfile { double n = 0, streaming = 0, alloc = 0, extract = 0, tail = 0, total = 0, gil_held = 0; };
@@ -142,8 +200,13 @@ PyObject* py_decode(PyObject*, PyObject* args) {
   // one (pointer, length) per record, uninitialised (2 x 8 bytes x n): every slot is written below.  A reference is
   // held on every bytes object while the GIL is released; the object is recovered from its payload pointer afterwards
   // (payload = object + offsetof(PyBytesObject, ob_sval)), so no third array is kept.
-  std::unique_ptr<const uint8_t*[]> ptrs(new const uint8_t*[(size_t)n + 1]);
-  std::unique_ptr<uint64_t[]> lens(new uint64_t[(size_t)n + 1]);
+  // (the two arrays come from a small cache kept between calls, guarded by the GIL: fresh ones cost a page fault per 4 KiB when
+  //  they are filled and a munmap when they are dropped -- 160 MB per 10M-record call, 17 ms of a 60 ms call on the GPU box,
+  //  scripts/host_gap_probe.py)
+  Scratch ptrs_s((size_t)n + 1), lens_s((size_t)n + 1);
+  if (!ptrs_s.ok() || !lens_s.ok()) return PyErr_NoMemory();
+  const uint8_t** const ptrs = ptrs_s.as<const uint8_t*>();
+  uint64_t* const lens = lens_s.as<uint64_t>();
   constexpr size_t kPayload = offsetof(PyBytesObject, ob_sval);
   auto drop_range = [&](Py_ssize_t from, Py_ssize_t upto) {
     constexpr Py_ssize_t kAheadD = 24;
@@ -207,7 +270,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     opts.gathered = reinterpret_cast<uint64_t*>(&gathered);
     try {
       worker = std::thread([&] {                     // (never touches Python)
-        rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+        rc = rh_decode(s, ptrs, lens, (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
         finished.store(true, std::memory_order_release);
       });
     } catch (const std::system_error&) {             // no thread to be had: the classic form below
@@ -345,7 +408,7 @@ PyObject* py_decode(PyObject*, PyObject* args) {
     t_tail = std::chrono::steady_clock::now();
     const auto t_rel = std::chrono::steady_clock::now();
     Py_BEGIN_ALLOW_THREADS   // py.detach(...), src/lib.rs:82-86
-    rc = rh_decode(s, ptrs.get(), lens.get(), (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
+    rc = rh_decode(s, ptrs, lens, (uint64_t)n, num_chunks, &opts, chunks, &out_k, want_stats ? &st : nullptr, &err);
     Py_END_ALLOW_THREADS
     ms_released = ms_since(t_rel);
     drop_range(0, n);

@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     assert cabi.lib().rh_abi_version() == 6
 
 
+def test_gather_pool_hands_out_every_task_exactly_once():
+    """The host thread pool behind the gather of pipelined calls (engine_host.cpp CallPool: lock-free phase hand-over, polling
+    workers that fall asleep between calls): many short phases, few and many workers, more workers than cores."""
+    f = C.CDLL(cabi.LIB_PATH).rh_selftest_pool
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    for workers, phases, max_tasks in ((1, 2000, 7), (3, 20000, 5), (8, 20000, 64), (32, 6000, 33), (64, 1500, 200)):
+        assert f(workers, phases, max_tasks) == 0, (workers, phases, max_tasks)
+
+
 def test_clamp_chunks_matches_reference():   # deserialize.rs:53-55
     f = cabi.lib().rh_clamp_chunks
     assert [f(10, k) for k in (0, 1, 3, 10, 11, 1000)] == [1, 1, 3, 10, 10, 10]
