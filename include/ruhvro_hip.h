@@ -260,10 +260,12 @@ uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 
 /* Measurement hook, not part of the drop-in surface: the host-side gather of a `shards`-GPU rh_decode call (every shard's
  * record slices copied into its staging buffer by its own host thread + `threads_per_shard` helpers, all shards at once)
- * without the GPUs -- pageable destinations (pinned = 0, runs on a box with no device) or pinned ones.  *best_ms = best
+ * without the GPUs -- pageable destinations (pinned = 0, runs on a box with no device), pinned ones (1), or pageable ones placed
+ * per NUMA node with the shard's threads bound there (2; rh_numa_nodes() = how many nodes the kernel shows).  *best_ms = best
  * wall time of `reps` rounds; returns the payload bytes per round, 0 on failure.  scripts/gather_scaling.py. */
 uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint32_t shards,
                          uint32_t threads_per_shard, int pinned, uint32_t reps, double* best_ms);
+uint32_t rh_numa_nodes(void);
 
 /* Test hook, not part of the drop-in surface: exercises the host thread pool behind the gather of pipelined calls (its
  * lock-free phase hand-over); 0 = every task of every phase ran exactly once.  tests/test_host.py. */

@@ -9,6 +9,8 @@
 // decode entry point fails with RH_ERR_RUNTIME.
 #include "engine_internal.h"
 
+#include <sched.h>
+
 using namespace rhe;
 
 // ===========================================================================
@@ -92,9 +94,38 @@ int rh_device_count(void) {
 // call do (gather_slices) -- into pageable memory (pinned = 0; needs no GPU) or pinned memory (pinned = 1).  Destinations
 // are allocated and touched before the clock starts.  Writes the best wall time of `reps` rounds to *best_ms and returns
 // the payload bytes gathered per round (0 on failure).
+// cpus of every NUMA node (from /sys/devices/system/node/node<N>/cpulist); empty when the kernel shows none
+static std::vector<std::vector<int>> numa_node_cpus() {
+  std::vector<std::vector<int>> nodes;
+  for (int nd = 0; nd < 64; nd++) {
+    FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(nd) + "/cpulist").c_str(), "r");
+    if (!f) break;
+    char buf[4096];
+    std::vector<int> cpus;
+    if (std::fgets(buf, sizeof buf, f)) {
+      for (char* p = buf; *p;) {
+        char* e = nullptr;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long z = a;
+        p = e;
+        if (*p == '-') { z = std::strtol(p + 1, &e, 10); p = e; }
+        for (long c = a; c <= z; c++) cpus.push_back((int)c);
+        if (*p == ',') p++;
+      }
+    }
+    std::fclose(f);
+    nodes.push_back(cpus);
+  }
+  return nodes;
+}
+
 uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint32_t shards, uint32_t threads_per_shard,
                          int pinned, uint32_t reps, double* best_ms) {
   if (!ptrs || !lens || !best_ms || shards == 0) return 0;
+  // pinned: 0 = pageable destinations, 1 = hipHostMalloc, 2 = pageable and NUMA-PLACED: shard j's host thread (and its helpers,
+  // which inherit the mask) is bound to the cpus of node j mod <nodes> and allocates + first-touches its destination there
+  const std::vector<std::vector<int>> nodes = pinned == 2 ? numa_node_cpus() : std::vector<std::vector<int>>();
   struct Dst { uint8_t* p = nullptr; uint64_t bytes = 0, rows0 = 0, rows = 0, o_off = 0; };
   std::vector<Dst> dst(shards);
   uint64_t total = 0;
@@ -107,24 +138,37 @@ uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint6
     total += b;
     d.o_off = align_up(16 + b + 32, kAlign);
     d.bytes = d.o_off + 8 * (d.rows + 1);
-    if (pinned) ok = ok && hipHostMalloc((void**)&d.p, d.bytes, hipHostMallocDefault) == hipSuccess;
+    if (pinned == 1) ok = ok && hipHostMalloc((void**)&d.p, d.bytes, hipHostMallocDefault) == hipSuccess;
     else ok = ok && posix_memalign((void**)&d.p, 4096, d.bytes) == 0;
-    if (ok) std::memset(d.p, 0, d.bytes);
+    if (ok && pinned != 2) std::memset(d.p, 0, d.bytes);
   }
+  auto bind = [&](unsigned j) {
+    if (nodes.size() < 2) return;
+    const std::vector<int>& cpus = nodes[j % nodes.size()];
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) if (c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof set, &set);
+  };
+  if (ok && pinned == 2)
+    run_threads(shards, [&](unsigned j) { bind(j); std::memset(dst[j].p, 0, dst[j].bytes); });     // first touch on the shard's node
   double best = 1e30;
   for (uint32_t r = 0; ok && r < std::max(reps, 1u); r++) {
     Timer t;
     run_threads(shards, [&](unsigned j) {
       Dst& d = dst[j];
+      if (pinned == 2) bind(j);
       gather_into(ptrs + d.rows0, lens + d.rows0, d.rows, threads_per_shard, d.p + 16, (uint64_t*)(d.p + d.o_off));
     });
     best = std::min(best, (double)t.ms());
   }
   for (Dst& d : dst)
-    if (d.p) { if (pinned) (void)hipHostFree(d.p); else std::free(d.p); }
+    if (d.p) { if (pinned == 1) (void)hipHostFree(d.p); else std::free(d.p); }
   *best_ms = best;
   return ok ? total : 0;
 }
+
+uint32_t rh_numa_nodes(void) { return (uint32_t)numa_node_cpus().size(); }
 
 int rh_current_device(void) {
   int n = 0, d = -1;

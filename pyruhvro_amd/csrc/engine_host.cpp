@@ -448,15 +448,18 @@ void decode_range(rh_schema* s, const Source& src, uint64_t r0, uint64_t r1, uin
   }
 }
 
-// Payload bytes from which a call is pipelined.  Measured on MI355X (profiles/r01h_pipeline_e2e.jsonl, 10M records,
-// 1.2 GB in / 1.7 GB out): with the records in PINNED memory (rh_decode packs them there) the two PCIe directions
-// overlap and H2D + kernels + D2H drop from 55 to 43 ms; from PAGEABLE memory (rh_decode_packed) the runtime's staged
-// H2D copies do not overlap with the D2H copies of other streams (56.5 vs 55.0 ms), and at 1M records the extra
-// streams / launches cost more than the overlap gains (7.1 vs 5.7 ms).  So: pinned source and >= 256 MB by default;
+// Payload bytes from which a call is pipelined (contiguous groups of chunks through gather -> H2D -> kernels on their own
+// streams).  Round 5, MI355X box (profiles/r05p_pipeline_threshold.txt): with the results written straight into pinned host
+// memory the pipeline pays from a few tens of MB -- record slices (gathered into pinned memory anyway): 32 MB 3.06 -> 2.1 ms,
+// 128 MB (1M benchmark records) 8.4 -> 5.4 ms; a packed payload in pageable memory (staged through pinned memory by the
+// call's threads when pipelined, one runtime-staged copy when not): 32 MB 1.52 -> 1.72 ms, 128 MB 5.67 -> 5.0 ms.
+// (Round 1 measured the opposite at 1M records, 7.1 vs 5.7 ms: the D2H copies of one group and the H2D copies of the next
+// then shared one copy queue and ran strictly one after the other, profiles/r05o_host_pipeline_trace_d2h_copies.txt.)
 // RUHVRO_HIP_PIPELINE_MIN_MB overrides the threshold for both sources (tests force 0).
-uint64_t pipeline_min_bytes(bool source_pinned) {      // read per call: tests switch it
+uint64_t pipeline_min_bytes(bool source_pinned, bool staged_pageable) {      // read per call: tests switch it
   if (const char* e = std::getenv("RUHVRO_HIP_PIPELINE_MIN_MB")) return (uint64_t)std::strtoull(e, nullptr, 10) << 20;
-  return source_pinned ? (256ull << 20) : ~0ull;
+  if (staged_pageable) return 96ull << 20;
+  return source_pinned ? (24ull << 20) : ~0ull;
 }
 
 // One contiguous run of a call's chunks, decoded by one host thread on one device with its own stream and arenas.
@@ -553,7 +556,7 @@ int decode_host_impl(rh_schema* s, const Source& src, uint64_t n, uint64_t num_c
     // Large calls on the default stream are pipelined: chunks are independent (deserialize.rs:92-120), so contiguous
     // groups of chunks go through H2D -> kernels -> D2H on their own streams, staggered so that the link carries one
     // group's results out while the next group's records come in.
-    const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned)) ? std::min<uint32_t>(k, 8) : 1;
+    const uint32_t groups = (user_stream == nullptr && k >= 2 && bytes >= pipeline_min_bytes(source_pinned, stage_packed)) ? std::min<uint32_t>(k, 8) : 1;
     if (groups <= 1) {
       decode_range(s, src, 0, n, num_chunks, nullptr, opts, device, user_stream, out_chunks, out_k, stats, nullptr, nullptr, 0,
                    bytes >= (4u << 20) ? std::min(hw, 16u) : 1u);

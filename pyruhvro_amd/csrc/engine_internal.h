@@ -127,6 +127,7 @@ class Pool {
   }
   Block get(uint64_t size, int device) {
     size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
+    if (fail_injected()) throw HipError(std::string("HIP allocation of ") + std::to_string(size) + " bytes failed: injected failure (RUHVRO_HIP_FAIL_ALLOC)");
     {
       std::lock_guard<std::mutex> g(mu_);
       int best = -1;
@@ -164,6 +165,19 @@ class Pool {
     if (host_) { std::memset(b.p, 0xA5, b.size); return; }
     (void)hipMemset(b.p, 0xA5, b.size);
     (void)hipDeviceSynchronize();
+  }
+  // RUHVRO_HIP_FAIL_ALLOC=N (test hook, read per request): the N-th block request from now on (N = 1: the next one), of either
+  // pool and whether or not a cached block would have served it, fails the way an exhausted device does -- what a call does with a failed hipMalloc half-way through its
+  // launch sequence (error class, no leaked lease, the next call unharmed: tests/test_round5.py).
+  static bool fail_injected() {
+    const char* e = std::getenv("RUHVRO_HIP_FAIL_ALLOC");
+    if (!e || !*e) return false;
+    static std::atomic<long> seen{0};
+    static std::atomic<long> armed{0};
+    const long n = std::atol(e);
+    if (n <= 0) return false;
+    if (armed.exchange(n) != n) seen.store(0);          // the hook was (re)set: count from here
+    return seen.fetch_add(1) + 1 == n;
   }
   // A cached block of a suitable size, or an empty Block: never allocates.
   Block try_get(uint64_t size, int device) {

@@ -34,7 +34,14 @@ def main():
            "what": "rh_bench_gather: g shards gather their contiguous share of the record slices at the same time, t helper threads per shard "
                    "(sum of lengths, then offsets + memcpy per record -- engine.cpp gather_into); GB/s = payload bytes / best wall time",
            "bar": "8 PCIe links x ~50 GB/s H2D = ~400 GB/s of gathered payload for 8 GPUs; one link ~50", "runs": []}
-    for pinned in ([0, 1] if have_gpu else [0]):
+    L.rh_numa_nodes.restype = C.c_uint32
+    out["numa_nodes"] = int(L.rh_numa_nodes())
+    try:
+        out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        out["cgroup_cpu_max"] = None
+    out["effective_cpus"] = int(L.rh_effective_cpus())
+    for pinned in ([0, 1, 2] if have_gpu else [0, 2]):
         for g in (1, 2, 4, 8):
             for t in sorted({1, 2, 4, 8, max(1, min(32, ncpu // g))}):
                 if g * t > 2 * ncpu:
@@ -43,11 +50,11 @@ def main():
                 b = L.rh_bench_gather(ptrs.ctypes.data, lens.ctypes.data, n, g, t, pinned, reps, C.byref(ms))
                 if not b:
                     continue
-                out["runs"].append({"shards": g, "threads_per_shard": t, "pinned": bool(pinned), "ms": round(ms.value, 3),
+                out["runs"].append({"shards": g, "threads_per_shard": t, "pinned": pinned == 1, "numa_placed": pinned == 2, "ms": round(ms.value, 3),
                                     "GBps": round(b / ms.value / 1e6, 2), "GBps_per_shard": round(b / ms.value / 1e6 / g, 2)})
     best = {}
     for r in out["runs"]:
-        key = f"g={r['shards']}{' pinned' if r['pinned'] else ' pageable'}"
+        key = f"g={r['shards']}{' pinned' if r['pinned'] else ' pageable, numa-placed' if r['numa_placed'] else ' pageable'}"
         if key not in best or r["GBps"] > best[key]["GBps"]:
             best[key] = r
     out["best"] = {k: {"threads_per_shard": v["threads_per_shard"], "GBps": v["GBps"], "ms": v["ms"]} for k, v in best.items()}

@@ -15,12 +15,18 @@ data, offsets = fastgen.generate("full", 10_000_000)
 recs = fastgen.split(data, offsets)
 out = {}
 ptrs = (np.uint64(data.ctypes.data) + offsets[:-1]).astype(np.uint64); lens = np.diff(offsets).astype(np.uint64)
-for m in (1_000_000, 10_000_000):
+for m in (250_000, 1_000_000, 10_000_000):
     best = 1e9
     for _ in range(5):
         t = time.perf_counter(); r = cabi.decode_slices(ptrs[:m], lens[:m], S, 8); w = time.perf_counter() - t; del r
         best = min(best, w)
     out["slices_%d" % m] = round(best * 1e3, 3)
+    best = 1e9
+    om = offsets[: m + 1]
+    for _ in range(5):
+        t = time.perf_counter(); r = cabi.decode_packed(data[: int(om[-1])], om, S, 8); w = time.perf_counter() - t; del r
+        best = min(best, w)
+    out["packed_%d" % m] = round(best * 1e3, 3)
 for m in (10_000, 1_000_000, 10_000_000):
     sub = recs[:m] if m < len(recs) else recs
     for _ in range(3): P.deserialize_array_threaded(sub, S, 8)

@@ -48,7 +48,7 @@ REAL_WORKER = textwrap.dedent("""
     from avrogen.schemas import SCHEMAS
     from oracle import c_walker
     from pyruhvro_amd import cabi
-    N, K = 20003, 8
+    N, K, WORLD = %d, 8, %d
     checked = {}
     def make_step(gen_cfg, shard, dev, local_rank):
         step, info = bench.gpu_step_factory(gen_cfg, shard, torch.device("cuda", 0), 0)
@@ -65,12 +65,12 @@ REAL_WORKER = textwrap.dedent("""
             assert_batches_identical(g, e)
         checked["batches"] = len(got); checked["rows"] = sum(b.num_rows for b in got)
         return step, info
-    args = bench.parse_args(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "full1m", "--records", str(N)])
+    args = bench.parse_args(["--gpus", str(WORLD), "--steps", "3", "--warmup", "1", "--workload", "full1m", "--records", str(N)])
     rank, world, wall, per_rank, agg, cfg = bench.run(args, make_step, backend="gloo")
     print("RESULT " + json.dumps({"rank": rank, "world": world, "per_rank": per_rank, "agg": agg, "checked": checked}))
     import torch.distributed as dist
     dist.destroy_process_group()
-""") % (ROOT, ROOT)
+""")
 
 
 def _free_port():
@@ -81,14 +81,14 @@ def _free_port():
     return p
 
 
-def _run_two_ranks(tmp_path, text):
+def _run_two_ranks(tmp_path, text, world=2):
     script = tmp_path / "worker.py"
     script.write_text(text)
     port = _free_port()
     procs = []
-    for r in range(2):
+    for r in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
-                   WORLD_SIZE="2")
+                   WORLD_SIZE=str(world))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -126,12 +126,27 @@ def test_two_rank_gloo_bench_plumbing(tmp_path, scaling):
 def test_two_ranks_real_decode_of_one_list(tmp_path):
     """Two processes (gloo rendezvous, both on device 0), each decoding its whole chunks of ONE 20003-record list and
     checking them against the oracle's chunks of the whole list: the config-5 path with a real decode under N > 1."""
-    outs = _run_two_ranks(tmp_path, REAL_WORKER)
+    outs = _run_two_ranks(tmp_path, REAL_WORKER % (ROOT, ROOT, 20003, 2))
     assert [o["checked"]["batches"] for o in outs] == [4, 4]
     assert sum(o["checked"]["rows"] for o in outs) == 20003
     for o in outs:
         assert [r["records"] for r in o["per_rank"]] == [10000, 10003]
         assert o["agg"]["records_total"] == 20003 * 3 and o["agg"]["emit_kernel_ms_max"] > 0
+
+
+@pytest.mark.gpu
+def test_eight_ranks_one_chunk_each_real_decode(tmp_path):
+    """BASELINE config 5's shape as far as one GPU can show it: EIGHT processes (gloo rendezvous, all on device 0), each holding
+    exactly one reference chunk of ONE list (rh_decode_device + rh_opts.chunk_rows), each checking its batch against the oracle's
+    chunk of the whole list; the stats all-gather and the MAX all-reduce run over the eight ranks (deserialize.rs:57-68, 92-120:
+    one task per chunk, ordered join -- here one process per chunk, stats only across them)."""
+    n = 400_003
+    outs = _run_two_ranks(tmp_path, REAL_WORKER % (ROOT, ROOT, n, 8), world=8)
+    assert [o["checked"]["batches"] for o in outs] == [1] * 8
+    assert [o["checked"]["rows"] for o in sorted(outs, key=lambda o: o["rank"])] == [n // 8] * 7 + [n - 7 * (n // 8)]
+    for o in outs:
+        assert o["world"] == 8 and [r["records"] for r in o["per_rank"]] == [n // 8] * 7 + [n - 7 * (n // 8)]
+        assert o["agg"]["records_total"] == n * 3 and o["agg"]["emit_kernel_ms_max"] > 0
 
 
 def test_sharding_helpers():

@@ -124,7 +124,8 @@ def test_current_device_is_resolved_on_the_calling_thread():
     of its own, where HIP's current device would be 0 again) decodes on it."""
     assert cabi.lib().rh_current_device() == torch.cuda.current_device()
     if torch.cuda.device_count() < 2:
-        pytest.skip("one GPU: the non-zero-device half of this test needs two")
+        pytest.skip("NOT RUN: ONE GPU VISIBLE.  The non-zero-device half of this test (a streaming call made with device 1 current must decode "
+                    "on device 1 and leave device 0 untouched) needs two GPUs -- on a multi-GPU box this skip must not appear")
     data, offsets = fastgen.generate("full", 70_000)
     recs = fastgen.split(data, offsets)
     torch.cuda.set_device(1)

@@ -109,3 +109,86 @@ def test_more_than_64_counters(case, kernel):
             assert_batches_identical(g, e)
     finally:
         P.set_kernel_mode(old)
+
+
+@pytest.mark.parametrize("n", [10_000, 100_000])
+def test_num_chunks_equal_to_the_record_count(n):
+    """deserialize.rs:53-55 lets num_chunks go up to n: n one-row batches.  Every chunk is a 256-byte-aligned region per Arrow buffer
+    and a workgroup of its own, so this is the engine's worst shape -- it has to work (and say what it cost), not be fast."""
+    data, offsets = fastgen.generate("full", n)
+    got, st = cabi.decode_packed(data, offsets, SCHEMAS["full"], n, want_stats=True)
+    assert len(got) == n and st["chunks"] == n and st["records"] == n
+    exp = c_walker.decode_packed(c_walker.CompiledSchema(SCHEMAS["full"]), data, offsets, n, threaded=False)
+    for i in list(range(0, n, max(1, n // 500))) + [n - 1]:
+        assert got[i].num_rows == 1
+        assert_batches_identical(got[i], exp[i])
+    assert st["total_ms"] < 20_000
+    print(f"num_chunks = n = {n}: engine {st['total_ms']:.0f} ms, {st['output_bytes']} Arrow bytes in {n} batches")
+
+
+def test_one_giant_record_among_small_ones():
+    """One 60 MB record (an array of 2M strings) among 100,000 ordinary ones (fast_decode.rs:703-719 walks it item by item): its
+    tile does not fit the LDS window and is walked from global memory by one lane per record.  Correct on both kernel forms, and
+    bounded: seconds, not minutes (profiles/r05t_giant_record_lookahead.txt has the numbers and why)."""
+    from avrogen.encoder import zigzag
+    n, items = 100_000, 2_000_000
+    data, offsets = fastgen.generate("full", n)
+    recs = fastgen.split(data, offsets)
+    body = bytearray(b"\x00\x00") + zigzag(items) + (zigzag(29) + b"x" * 29) * items + b"\x00" + b"\x00\x00\x00\x00" + \
+        zigzag(1_750_000_000) + zigzag(1)
+    recs[n // 2] = bytes(body)
+    exp = c_walker.decode_threaded(recs, SCHEMAS["full"], 8)
+    for mode in ("generic", "specialized"):
+        old = P.set_kernel_mode(mode)
+        try:
+            t0 = time.perf_counter()
+            got = P.deserialize_array_threaded(recs, SCHEMAS["full"], 8)
+            wall = time.perf_counter() - t0
+        finally:
+            P.set_kernel_mode(old)
+        for g, e in zip(got, exp):
+            assert_batches_identical(g, e)
+        assert wall < 30, f"{mode}: {wall:.1f} s"
+
+
+def test_allocation_failure_is_an_error_not_a_leak(monkeypatch):
+    """RUHVRO_HIP_FAIL_ALLOC=N fails the N-th fresh pool allocation the way an exhausted device does.  Whatever stage of the launch
+    sequence it hits: RuntimeError (RH_ERR_RUNTIME), the leases taken so far go back to their pools, and the next call is fine."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free0, total = ctypes.c_size_t(), ctypes.c_size_t()
+    n = 300_000
+    data, offsets = fastgen.generate("cfg3", n)
+    d_data, d_off = _to_device(data, offsets)
+    exp = c_walker.decode_packed(c_walker.CompiledSchema(SCHEMAS["cfg3"]), data, offsets, 4, threaded=True)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(schema, host):
+        if host:
+            return cabi.decode_packed(data, offsets, schema, 4)
+        r = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), int(offsets[-1]), n, schema, 4, device=0, stream=stream)
+        try:
+            return r.to_host()
+        finally:
+            r.free()
+
+    failures = 0
+    for host in (False, True):
+        for nth in range(1, 9):
+            # a payload size of its own per attempt: the pools hold no block of a fitting class, so fresh allocations happen
+            schema = SCHEMAS["cfg3"] + " " * (7 + nth + (20 if host else 0))
+            monkeypatch.setenv("RUHVRO_HIP_FAIL_ALLOC", str(nth))
+            try:
+                got = call(schema, host)
+            except RuntimeError as e:
+                assert "injected failure" in str(e)
+                failures += 1
+                got = None
+            monkeypatch.delenv("RUHVRO_HIP_FAIL_ALLOC")
+            if got is None:
+                got = call(schema, host)                 # the very next call on the same schema works
+            for g, e in zip(got, exp):
+                assert_batches_identical(g, e)
+    assert failures >= 2, failures                      # the hook really hit allocations of live calls
+    hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total))
+    assert free0.value > 0

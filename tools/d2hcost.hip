@@ -41,6 +41,21 @@ int main() {
     free(pg);
     printf("%4zu MB: D2H->pinned(warm) %.2f ms (%.1f GB/s) | hipHostMalloc %.2f ms, first D2H into it %.2f ms, hipHostFree %.2f | D2H->pageable cold %.2f ms (%.1f GB/s) warm %.2f | "
            "hipHostRegister %.2f ms + D2H %.2f + unregister %.2f\n", mb, pinned, n / pinned / 1e6, hm, first, hf, page_cold, n / page_cold / 1e6, page_warm, reg, reg_copy, unreg);
+    {   // both directions at once, pinned on both sides, two streams: is the link full duplex for the copy engines?
+      hipStream_t st2; CK(hipStreamCreate(&st2));
+      void* up; CK(hipHostMalloc(&up, n, 0)); memset(up, 2, n);
+      void* d2; CK(hipMalloc(&d2, n));
+      CK(hipMemcpyAsync(d2, up, n, hipMemcpyHostToDevice, st2)); CK(hipStreamSynchronize(st2));
+      t = now(); CK(hipMemcpyAsync(d2, up, n, hipMemcpyHostToDevice, st2)); CK(hipStreamSynchronize(st2)); const double h2d_alone = now() - t;
+      t = now();
+      CK(hipMemcpyAsync(d2, up, n, hipMemcpyHostToDevice, st2));
+      CK(hipMemcpyAsync(warm, d, n, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st2)); const double h2d_both = now() - t;
+      CK(hipStreamSynchronize(st)); const double both = now() - t;
+      printf("  duplex %zu MB each way: H2D alone %.2f ms (%.1f GB/s), D2H alone %.2f ms; together: H2D done at %.2f ms, both at %.2f ms = %.1f GB/s combined\n",
+             mb, h2d_alone, n / h2d_alone / 1e6, pinned, h2d_both, both, 2.0 * n / both / 1e6);
+      CK(hipFree(d2)); CK(hipHostFree(up)); CK(hipStreamDestroy(st2));
+    }
     CK(hipHostFree(warm)); CK(hipFree(d));
   }
   return 0;
