@@ -193,6 +193,12 @@ uint64_t rh_device_result_output_bytes(const rh_device_result* r);
 /* Arrow C Device Data Interface view of chunk i (device_type ARROW_DEVICE_ROCM);
  * valid until rh_device_result_free; release the view through array.release. */
 int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDeviceArray* out);
+/* ABI version 6.  The device buffers of chunk i with their byte sizes (the Arrow C Device Data structs carry pointers and lengths
+ * only): fills ptrs[] / sizes[] (either may be NULL) with up to `cap` entries, one per Arrow buffer of the schema, and returns how
+ * many buffers a chunk has.  sizes[] are the bytes the engine reserved for the buffer (offsets: 4 x (rows + 1); bitmaps: whole
+ * 64-bit words; data: the column's bytes), so a consumer can wrap buffers_of(export(i)) as typed device arrays without reading
+ * an offsets buffer back -- what pyruhvro_amd.deserialize_to_device does for DLPack consumers.  0 on error. */
+uint32_t rh_device_result_buffers(rh_device_result* r, uint32_t chunk, uint64_t* ptrs, uint64_t* sizes, uint32_t cap);
 /* Copy the chunks to host memory (same form rh_decode returns). */
 int rh_device_result_to_host(rh_device_result* r, struct ArrowArray* out_chunks, char** err);
 void rh_device_result_free(rh_device_result* r);

@@ -267,6 +267,14 @@ def device_count() -> int:
     return _require_native().device_count()
 
 
+def deserialize_to_device(records, schema, num_chunks, device: int = -1, stream: int = 0):
+    """Extension: the same decode with the Arrow buffers left in HBM, every buffer a DLPack producer
+    (``torch.from_dlpack(dec.batches[0].column("created_at").values)`` is an int64 tensor over the engine's memory, no copy).
+    See ``pyruhvro_amd.device``."""
+    from .device import deserialize_to_device as f
+    return f(records, schema, num_chunks, device=device, stream=stream, kernel=_kernel_mode)
+
+
 def kernels_ready(schema: str, encode: bool = False, timeout_ms: int = 0) -> bool:
     """Extension.  A schema this process has not met is decoded by the generic kernels at once while the kernels specialised
     to it compile in the background (the reference's cost of a new schema is a JSON parse, ``src/lib.rs:39-54``; a hiprtc
@@ -286,5 +294,5 @@ __all__ = [
     "deserialize_array", "deserialize_array_threaded", "deserialize_array_threaded_spawn",
     "serialize_record_batch_with_stats",
     "serialize_record_batch", "serialize_record_batch_spawn", "arrow_schema", "device_count", "set_kernel_mode",
-    "deserialize_binary_array", "set_devices", "kernels_ready", "prebuild",
+    "deserialize_binary_array", "set_devices", "kernels_ready", "prebuild", "deserialize_to_device",
 ]

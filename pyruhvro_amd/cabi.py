@@ -111,6 +111,8 @@ def lib():
         L.rh_device_result_export.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ArrowDeviceArray)]
         L.rh_device_result_to_host.argtypes = [C.c_void_p, C.POINTER(ArrowArray), C.POINTER(C.c_char_p)]
         L.rh_device_result_free.argtypes = [C.c_void_p]
+        L.rh_device_result_buffers.restype = C.c_uint32
+        L.rh_device_result_buffers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]
         L.rh_free_string.argtypes = [C.c_void_p]
         L.rh_schema_kernel_source.restype = C.c_void_p
         L.rh_schema_kernel_source.argtypes = [C.c_void_p]

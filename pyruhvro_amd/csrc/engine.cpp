@@ -353,6 +353,25 @@ int rh_device_result_export(rh_device_result* r, uint32_t chunk, struct ArrowDev
   return RH_OK;
 }
 
+uint32_t rh_device_result_buffers(rh_device_result* r, uint32_t chunk, uint64_t* ptrs, uint64_t* sizes, uint32_t cap) {
+  if (!r || chunk >= r->k) return 0;
+  try {
+    settle(r);
+    rh_device_result* owner = r;
+    for (size_t g = 0; g < r->parts.size(); g++)
+      if (chunk >= r->part_chunk0[g] && chunk < r->part_chunk0[g] + r->parts[g]->k) { owner = r->parts[g].get(); chunk -= r->part_chunk0[g]; break; }
+    owner->tables();
+    const uint32_t nbuf = (uint32_t)owner->cs->bufs.size();
+    for (uint32_t b = 0; b < nbuf && b < cap; b++) {
+      if (ptrs) ptrs[b] = (uint64_t)(uintptr_t)(owner->arena.ptr() + owner->buf_off[(size_t)b * owner->k + chunk]);
+      if (sizes) sizes[b] = owner->buf_size[(size_t)b * owner->k + chunk];
+    }
+    return nbuf;
+  } catch (...) {
+    return 0;
+  }
+}
+
 int rh_device_result_to_host(rh_device_result* r, struct ArrowArray* out_chunks, char** err) {
   if (!r || !out_chunks) return RH_ERR_ARGUMENT;
   return guarded(err, [&] { return to_host_impl(r, out_chunks); });
