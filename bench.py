@@ -518,9 +518,14 @@ def gpu_step_factory(gen_cfg, shard, dev, local_rank):
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
     torch.cuda.synchronize()
     schema = SCHEMAS[gen_cfg]
+    # what a service does at start-up when it wants its first batch at full speed (rh_schema_prebuild): the specialised kernels of
+    # this schema, all of them, compiled now if the kernel cache does not hold them -- a call that misses the cache would otherwise
+    # run on the generic kernels while they compile in the background (measured separately: `cold_start`)
+    t_pre = time.perf_counter()
+    info_prebuild_cached = cabi.prebuild(schema)
     stream = torch.cuda.current_stream().cuda_stream
     data_len = int(offsets[-1])
-    info = {"input_bytes": data_len, "output_bytes": 0}
+    info = {"input_bytes": data_len, "output_bytes": 0, "prebuild_s": round(time.perf_counter() - t_pre, 3), "prebuild_cached": bool(info_prebuild_cached)}
 
     # every ctypes argument is built once (cabi.PreparedDeviceDecode): a timed step is the C entry point, the wait and the free
     extra = [torch.cuda.Stream(device=dev) for _ in range(max(STREAMS, 1) - 1)]
