@@ -315,7 +315,9 @@ struct rh_decode_call {
     o_tick = o_tot + 8ull * K * k;                    // [k] tile tickets of the single-pass form (zero like the rest of the block)
     o_null = align_up(o_tick + 4ull * k, 16);
     null_slots = rh::null_slots_for(k);
-    ctrl_bytes = align_up(o_null + 4ull * nnodes * k * null_slots, kAlign);
+    // (with one null-count slot -- k > 2048 chunks -- the slot area is no larger than the compact host layout, whose publish
+    //  token sits behind the summed counts: room for it, whatever the rounding)
+    ctrl_bytes = align_up(std::max<uint64_t>(o_null + 4ull * nnodes * k * null_slots, align_up(o_null + 4ull * nnodes * k, 8) + 8), kAlign);
     const uint64_t o_err = 0;       // the rest lives in the workspace (needs no zeroing)
     const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
@@ -674,13 +676,16 @@ hipEvent_t pooled_event(int device) {
   return e;
 }
 
-// the internal streams that accompany one caller stream on one device (created on first use, kept for the process)
-std::vector<hipStream_t> companion_streams(int device, hipStream_t caller, unsigned want) {
+// The internal streams of the in-call split on one device: created on first use, kept for the process, shared by every caller
+// stream of that device (a split call forks into them from its own stream with an event and joins them back the same way, so
+// they carry no caller's identity -- keyed by the caller's handle, as they were, a destroyed and re-created stream found stale
+// companions and the 65th caller silently lost the split).  Calls that split at the same time on one device
+// share them in stream order.
+std::vector<hipStream_t> companion_streams(int device, hipStream_t /*caller*/, unsigned want) {
   static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, std::vector<hipStream_t>> all;
+  static std::map<int, std::vector<hipStream_t>> all;
   std::lock_guard<std::mutex> g(mu);
-  if (all.size() >= 64 && !all.count({device, caller})) return {};          // a caller that burns through streams: no split
-  auto& v = all[{device, caller}];
+  auto& v = all[device];
   while (v.size() < want) {
     hipStream_t x = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
