@@ -43,7 +43,7 @@ def test_first_large_call_of_a_new_schema_does_not_wait_for_the_compiler(tmp_pat
     # the process has decoded before (generic kernels loaded, pools warm): what is new is the SCHEMA
     cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), int(offsets[-1]), n, SCHEMAS["full"], 8, device=0, stream=stream,
                        kernel=cabi.KERNEL_GENERIC).free()
-    schema = SCHEMAS["full"] + "   "                                   # a handle of this test's own (handles remember code objects)
+    schema = SCHEMAS["full"] + "\t\t"                                 # a handle of this test's own (handles remember code objects)
     before = cabi.engine_counters()["background_compiles"]
     t0 = time.perf_counter()
     r1 = cabi.decode_device(d_data.data_ptr(), d_off.data_ptr(), int(offsets[-1]), n, schema, 8, device=0, stream=stream)
@@ -78,7 +78,7 @@ def test_python_surface_on_a_cold_schema(tmp_path, monkeypatch):
     monkeypatch.setenv("RUHVRO_HIP_KERNEL_CACHE", str(tmp_path))
     data, offsets = fastgen.generate("cfg3", 60_000)
     recs = fastgen.split(data, offsets)
-    schema = SCHEMAS["cfg3"] + "    "
+    schema = SCHEMAS["cfg3"] + "\t\t\t"
     t0 = time.perf_counter()
     got, st = P.deserialize_array_threaded_with_stats(recs, schema, 4)
     ms = (time.perf_counter() - t0) * 1e3
@@ -176,7 +176,7 @@ def test_allocation_failure_is_an_error_not_a_leak(monkeypatch):
     for host in (False, True):
         for nth in range(1, 9):
             # a payload size of its own per attempt: the pools hold no block of a fitting class, so fresh allocations happen
-            schema = SCHEMAS["cfg3"] + " " * (7 + nth + (20 if host else 0))
+            schema = SCHEMAS["cfg3"] + "\t" * (7 + nth + (20 if host else 0))
             monkeypatch.setenv("RUHVRO_HIP_FAIL_ALLOC", str(nth))
             try:
                 got = call(schema, host)

@@ -63,10 +63,15 @@ def test_single_pass_is_identical_to_the_oracle(name, n, k):
     _check(_call(res, n, schema, k), exp)                               # the single pass
     _check(_call(res, n, schema, k, asynchronous=True), exp)            # ... settled by its first accessor
     d = _delta(c0)
-    assert d["single_pass_calls"] == 2 and d["single_pass_failovers"] == 0
+    # (a call whose chunks are so small that the k x K capacities do not fit the workspace's blocksum area -- fewer than two tiles
+    #  per chunk on average -- stays on the two-pass form: since round 5 that is decided before anything is counted or leased)
+    sz, last = n // k, n - (k - 1) * (n // k)
+    nblocks = (k - 1) * ((sz + 255) // 256) + (last + 255) // 256
+    want = 2 if 2 * k <= nblocks else 0
+    assert d["single_pass_calls"] == want and d["single_pass_failovers"] == 0
     _check(_call(res, n, schema, k, two_pass=True), exp)                # RH_TWO_PASS: the caller's choice
     _check(_call(res, n, schema, k, single_pass=False), exp)            # neither flag: the default is the two-pass form
-    assert _delta(c0)["single_pass_calls"] == 2
+    assert _delta(c0)["single_pass_calls"] == want
 
 
 def test_single_pass_at_one_million_records_full_buffer_identity():
