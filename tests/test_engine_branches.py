@@ -1,4 +1,4 @@
-"""The engine's rarely taken branches (engine.cpp decode_device_impl1), each forced with its test hook and PROVEN taken
+"""The engine's rarely taken branches (engine_device_call.cpp decode_device_impl1), each forced with its test hook and PROVEN taken
 through rh_engine_counters: the arena-capacity retry (LF_CAPACITY), the wide-index fallback to the generic kernels
 (NeedWideIndex / LF_NEED_WIDE), the 32-bit Arrow offset overflow (LF_OFFSET32) on a real > 2 GiB column, and the
 two-submission path (RUHVRO_HIP_TWO_SYNC) over the parity matrix.  Needs an MI355X."""

@@ -240,7 +240,7 @@ def test_chunk_semantics():
 
 @pytest.fixture
 def pipelined(monkeypatch):
-    """Force the pipelined host path (groups of chunks on their own streams, engine.cpp decode_packed_impl) on small
+    """Force the pipelined host path (groups of chunks on their own streams, engine_host.cpp decode_host_impl) on small
     inputs; by default it starts at 64 MB per call (the 1M / 10M config tests below run it at its default)."""
     monkeypatch.setenv("RUHVRO_HIP_PIPELINE_MIN_MB", "0")
 

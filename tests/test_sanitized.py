@@ -1,6 +1,6 @@
 """The engine under AddressSanitizer + UndefinedBehaviorSanitizer (`_build.build_sanitized`).
 
-engine.cpp manages lifetimes by hand (memory pools, leases, turnstiles, Arrow release callbacks shared by k chunks,
+The engine (csrc/engine_*.cpp) manages lifetimes by hand (memory pools, leases, turnstiles, Arrow release callbacks shared by k chunks,
 malloc'd error strings).  A child interpreter preloads the ASan runtime and loads the sanitizer build of
 libruhvro_hip.so in place of the normal one (RUHVRO_HIP_LIB for the ctypes view, LD_LIBRARY_PATH for the CPython
 extension's NEEDED entry), then runs

@@ -1,4 +1,4 @@
-"""The single-pass form of the device-resident decode (spec_body.h spec_fused; engine.cpp rh_decode_call::try_single): ONE kernel
+"""The single-pass form of the device-resident decode (spec_body.h spec_fused; engine_device_call.cpp rh_decode_call::try_single): ONE kernel
 sizes a tile, scans across the tiles of its chunk (decoupled look-back) and emits out of the same LDS window.  Opt-in
 (RH_SINGLE_PASS in rh_opts.flags).  A schema's first call has no size history and takes the two-pass form; every later one the single pass -- proven through
 rh_engine_counters -- and produces the same buffers (oracle: ruhvro/src/fast_decode.rs:570-922 restated), the same error
