@@ -277,7 +277,10 @@ int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
   if (!s) return RH_ERR_ARGUMENT;
   return guarded(err, [&] {
     // every kernel of the schema, each its own compile job, side by side (kernel_jobs.h); waits for all of them
-    const unsigned parts = rh::kDecodeParts | (s->cs->encode_unsupported.empty() ? rh::kEncodeParts : 0u);
+    // (RUHVRO_HIP_PREBUILD_FUSED=0: without the opt-in single-pass kernel -- the most expensive of the five, compiled on its first
+    //  use otherwise; build() warms the cache that way for the schemas no single-pass test or bench line uses)
+    const bool fused = env_long("RUHVRO_HIP_PREBUILD_FUSED", 1, 0, 1) != 0;
+    const unsigned parts = (rh::kDecodeParts & ~(fused ? 0u : (1u << rh::KP_FUSED))) | (s->cs->encode_unsupported.empty() ? rh::kEncodeParts : 0u);
     rh::KernelImage im[rh::KP_COUNT];
     const unsigned started = rh::kernel_images(s->images, *s->cs, parts, rh::CP_BLOCKING, im);
     for (int p = 0; p < rh::KP_COUNT; p++) {

@@ -92,8 +92,12 @@ def test_python_surface_on_a_cold_schema(tmp_path, monkeypatch):
         assert_batches_identical(g, e)
 
 
-@pytest.mark.parametrize("kernel", ["generic", "specialized"])
-@pytest.mark.parametrize("case", cases.wide_counter_cases(), ids=lambda c: c[0])
+# (the 96-counter schema's specialised emit kernel is a 2 MB code object that takes hiprtc five to eight minutes: the 70-counter
+#  schema covers the specialised kernels' counters 64..69, the 96-counter one the engine's limit, on the generic form)
+_WIDE = [(c, k) for c in cases.wide_counter_cases() for k in ("generic", "specialized") if not (k == "specialized" and "96" in c[0])]
+
+
+@pytest.mark.parametrize("case,kernel", _WIDE, ids=[f"{c[0]}-{k}" for c, k in _WIDE])
 def test_more_than_64_counters(case, kernel):
     _, schema, recs = case
     old = P.set_kernel_mode(kernel)
