@@ -196,3 +196,30 @@ def test_allocation_failure_is_an_error_not_a_leak(monkeypatch):
     assert failures >= 2, failures                      # the hook really hit allocations of live calls
     hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total))
     assert free0.value > 0
+
+
+@pytest.mark.parametrize("n", [20_000, 300_000])
+def test_results_kept_alive_across_calls_stay_intact(n):
+    """Host calls write their results straight into pooled pinned host memory and LEND the block to the batches (no D2H copy); a
+    dropped result returns its block to the pool, where the next call's emit kernel writes into it.  A caller that keeps batches
+    alive across many calls (the pool runs dry: pageable fallback, background refill) while dropping others (blocks recycled under
+    live neighbours) must find exactly the oracle's bytes in EVERY batch it still holds -- a recycled block under a live result
+    would show here.  20k records: one chunk group; 300k: pipelined chunk groups."""
+    schema = SCHEMAS["full"]
+    kept = []
+    for i in range(12):
+        data, offsets = fastgen.generate("full", n, start=i * n)              # different records every call
+        recs = fastgen.split(data, offsets)
+        got = P.deserialize_array_threaded(recs, schema, 8)
+        kept.append((i, got, c_walker.decode_packed(c_walker.CompiledSchema(schema), data, offsets, 8, threaded=True)))
+        if i % 3 == 2:
+            del kept[len(kept) // 2]                                           # let go of one in the middle
+        if i % 4 == 3:
+            for _, g, e in kept:                                               # and look at everything still held, mid-way
+                for a, b in zip(g, e):
+                    assert_batches_identical(a, b)
+    assert len(kept) == 8
+    for _, g, e in kept:
+        for a, b in zip(g, e):
+            a.validate(full=True)
+            assert_batches_identical(a, b)

@@ -183,3 +183,31 @@ def test_specialised_kernels_of_the_benchmark_schema_stay_in_registers(tmp_path,
         assert md["vgpr_count"] <= 128, (name, md)
     assert notes["rh_spec_emit"]["sgpr_spill_count"] <= 110, notes["rh_spec_emit"]
     assert notes["rh_spec_size"]["sgpr_spill_count"] == 0 and notes["rh_espec_emit"]["sgpr_spill_count"] == 0
+
+
+def test_processes_that_meet_a_new_schema_together_compile_it_once(tmp_path):
+    """Eight ranks of one job meet a new schema at the same moment (BASELINE config 5): every process starts its compile helpers,
+    which serialise on a lock file next to each code object -- one compiles, the others find the object there -- and every process
+    ends up with the five kernels, nothing left behind."""
+    code = ("import os; from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS\n"
+            "cabi.prebuild(SCHEMAS['t_union'])\n"
+            "assert cabi.kernels_ready(SCHEMAS['t_union']) and cabi.kernels_ready(SCHEMAS['t_union'], encode=True)\n")
+    env = dict(os.environ, RUHVRO_HIP_KERNEL_CACHE=str(tmp_path), RUHVRO_HIP_COMPILE_JOBS="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, cwd=root) for _ in range(4)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0, 0, 0]
+    left = sorted(os.listdir(tmp_path))
+    assert len(left) == 5 and all(f.endswith(".hsaco") for f in left), left
+
+
+def test_unwritable_kernel_cache_falls_back_to_a_private_directory(tmp_path):
+    """An installation whose kernel cache cannot be written (a read-only site-packages; here: a path that is a FILE, which stops
+    root too) still compiles: the jobs work in a private temporary directory of the process, and the caller gets its kernels."""
+    blocked = tmp_path / "not_a_directory"
+    blocked.write_text("x")
+    code = ("from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS\n"
+            "assert cabi.prebuild(SCHEMAS['t_enum']) is False\n"
+            "assert cabi.kernels_ready(SCHEMAS['t_enum'])\n")
+    env = dict(os.environ, RUHVRO_HIP_KERNEL_CACHE=str(blocked))
+    subprocess.check_call([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert blocked.read_text() == "x"
