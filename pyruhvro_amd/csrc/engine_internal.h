@@ -111,6 +111,10 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 // caching device / pinned-host pools (one per process; blocks are reused across calls so a
 // steady-state decode does no hipMalloc)
 // ---------------------------------------------------------------------------
+// Pinned host blocks are written by kernels of ANY device of a multi-GPU call (control words, and the Arrow buffers themselves
+// when a host call's results go straight into pinned memory): visible to every device, mapped into their address spaces.
+constexpr unsigned kPinnedFlags = hipHostMallocPortable | hipHostMallocMapped;
+
 struct Block {
   void* p = nullptr;
   uint64_t size = 0;
@@ -147,10 +151,10 @@ class Pool {
     Block b;
     b.size = size;
     b.device = device;
-    hipError_t e = host_ ? hipHostMalloc(&b.p, size, hipHostMallocDefault) : hipMalloc(&b.p, size);
+    hipError_t e = host_ ? hipHostMalloc(&b.p, size, kPinnedFlags) : hipMalloc(&b.p, size);
     if (e != hipSuccess) {
       trim(0);
-      e = host_ ? hipHostMalloc(&b.p, size, hipHostMallocDefault) : hipMalloc(&b.p, size);
+      e = host_ ? hipHostMalloc(&b.p, size, kPinnedFlags) : hipMalloc(&b.p, size);
     }
     if (e != hipSuccess) throw HipError(std::string("HIP allocation of ") + std::to_string(size) + " bytes failed: " + hipGetErrorString(e));
     poison(b);

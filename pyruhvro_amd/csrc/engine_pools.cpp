@@ -61,7 +61,7 @@ void Pool::prefetch(uint64_t size, int device, uint64_t budget_left) {
         Block b;
         b.size = job.first;
         b.device = job.second;
-        if (hipHostMalloc(&b.p, b.size, hipHostMallocDefault) == hipSuccess) put(b);
+        if (hipHostMalloc(&b.p, b.size, kPinnedFlags) == hipSuccess) put(b);
         else (void)hipGetLastError();
         std::lock_guard<std::mutex> l(q.mu);
         q.queued_bytes -= job.first;
