@@ -94,38 +94,12 @@ int rh_device_count(void) {
 // call do (gather_slices) -- into pageable memory (pinned = 0; needs no GPU) or pinned memory (pinned = 1).  Destinations
 // are allocated and touched before the clock starts.  Writes the best wall time of `reps` rounds to *best_ms and returns
 // the payload bytes gathered per round (0 on failure).
-// cpus of every NUMA node (from /sys/devices/system/node/node<N>/cpulist); empty when the kernel shows none
-static std::vector<std::vector<int>> numa_node_cpus() {
-  std::vector<std::vector<int>> nodes;
-  for (int nd = 0; nd < 64; nd++) {
-    FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(nd) + "/cpulist").c_str(), "r");
-    if (!f) break;
-    char buf[4096];
-    std::vector<int> cpus;
-    if (std::fgets(buf, sizeof buf, f)) {
-      for (char* p = buf; *p;) {
-        char* e = nullptr;
-        const long a = std::strtol(p, &e, 10);
-        if (e == p) break;
-        long z = a;
-        p = e;
-        if (*p == '-') { z = std::strtol(p + 1, &e, 10); p = e; }
-        for (long c = a; c <= z; c++) cpus.push_back((int)c);
-        if (*p == ',') p++;
-      }
-    }
-    std::fclose(f);
-    nodes.push_back(cpus);
-  }
-  return nodes;
-}
-
 uint64_t rh_bench_gather(const uint8_t* const* ptrs, const uint64_t* lens, uint64_t n, uint32_t shards, uint32_t threads_per_shard,
                          int pinned, uint32_t reps, double* best_ms) {
   if (!ptrs || !lens || !best_ms || shards == 0) return 0;
   // pinned: 0 = pageable destinations, 1 = hipHostMalloc, 2 = pageable and NUMA-PLACED: shard j's host thread (and its helpers,
   // which inherit the mask) is bound to the cpus of node j mod <nodes> and allocates + first-touches its destination there
-  const std::vector<std::vector<int>> nodes = pinned == 2 ? numa_node_cpus() : std::vector<std::vector<int>>();
+  const std::vector<std::vector<int>> nodes = pinned == 2 ? numa_node_cpus() : std::vector<std::vector<int>>();      // (engine_pools.cpp)
   struct Dst { uint8_t* p = nullptr; uint64_t bytes = 0, rows0 = 0, rows = 0, o_off = 0; };
   std::vector<Dst> dst(shards);
   uint64_t total = 0;

@@ -103,6 +103,11 @@ inline long env_long_early(const char* name, long dflt, long lo, long hi) {
 // idle threads here sleep instead of polling; the gather pool's bursts are sized by the hardware threads.
 // RUHVRO_HIP_CPUS overrides.
 unsigned effective_cpus();
+const std::vector<std::vector<int>>& numa_node_cpus();      // cpus of every NUMA node (sysfs); empty when the kernel shows none
+int device_numa_node(int device);                           // NUMA node of a HIP device, -1 unknown
+void bind_thread_to_node(int node);                         // sched_setaffinity to that node's cpus (cached per thread)
+// pinned blocks are pooled per NUMA node of the device they were allocated under (hipHostMalloc places them there)
+inline int pin_key(int device) { const int n = device_numa_node(device); return n < 0 ? 0 : n; }
 
 constexpr uint64_t kAlign = 256;
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -131,12 +136,13 @@ class Pool {
   }
   Block get(uint64_t size, int device) {
     size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
+    if (host_) device = pin_key(device);        // (pinned blocks: the NUMA node of the device; allocated with that device current)
     if (fail_injected()) throw HipError(std::string("HIP allocation of ") + std::to_string(size) + " bytes failed: injected failure (RUHVRO_HIP_FAIL_ALLOC)");
     {
       std::lock_guard<std::mutex> g(mu_);
       int best = -1;
       for (size_t i = 0; i < free_.size(); i++) {
-        if ((host_ || free_[i].device == device) && free_[i].size >= size && free_[i].size <= size * 2 + (1 << 20)) {
+        if (free_[i].device == device && free_[i].size >= size && free_[i].size <= size * 2 + (1 << 20)) {
           if (best < 0 || free_[i].size < free_[best].size) best = (int)i;
         }
       }
@@ -186,10 +192,11 @@ class Pool {
   // A cached block of a suitable size, or an empty Block: never allocates.
   Block try_get(uint64_t size, int device) {
     size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
+    if (host_) device = pin_key(device);
     std::lock_guard<std::mutex> g(mu_);
     int best = -1;
     for (size_t i = 0; i < free_.size(); i++)
-      if ((host_ || free_[i].device == device) && free_[i].size >= size && free_[i].size <= size * 2 + (1 << 20))
+      if (free_[i].device == device && free_[i].size >= size && free_[i].size <= size * 2 + (1 << 20))
         if (best < 0 || free_[i].size < free_[best].size) best = (int)i;
     if (best < 0) return Block();
     Block b = free_[best];

@@ -4,6 +4,9 @@
 
 #include <sched.h>
 
+#include <cctype>
+#include <map>
+
 #include <cmath>
 #include <fstream>
 
@@ -37,9 +40,10 @@ void Pool::prefetch(uint64_t size, int device, uint64_t budget_left) {
   if (!host_) return;
   size = align_up(std::max<uint64_t>(size, 1), 1 << 16);
   {
+    const int key = pin_key(device);
     std::lock_guard<std::mutex> g(mu_);
     for (const Block& b : free_)
-      if (b.size >= size && b.size <= size * 2 + (1 << 20)) return;       // one is there
+      if (b.device == key && b.size >= size && b.size <= size * 2 + (1 << 20)) return;       // one is there
   }
   Refill& r = refill();
   std::lock_guard<std::mutex> g(r.mu);
@@ -61,6 +65,8 @@ void Pool::prefetch(uint64_t size, int device, uint64_t budget_left) {
         Block b;
         b.size = job.first;
         b.device = job.second;
+        (void)hipSetDevice(job.second);                  // (placement follows the current device)
+        b.device = pin_key(job.second);
         if (hipHostMalloc(&b.p, b.size, kPinnedFlags) == hipSuccess) put(b);
         else (void)hipGetLastError();
         std::lock_guard<std::mutex> l(q.mu);
@@ -69,6 +75,75 @@ void Pool::prefetch(uint64_t size, int device, uint64_t budget_left) {
     }).detach();
   }
   r.cv.notify_one();
+}
+
+// cpus of every NUMA node (from /sys/devices/system/node/node<N>/cpulist); empty when the kernel shows none
+const std::vector<std::vector<int>>& numa_node_cpus() {
+  static const std::vector<std::vector<int>> cached = [] {
+  std::vector<std::vector<int>> nodes;
+  for (int nd = 0; nd < 64; nd++) {
+    FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(nd) + "/cpulist").c_str(), "r");
+    if (!f) break;
+    char buf[4096];
+    std::vector<int> cpus;
+    if (std::fgets(buf, sizeof buf, f)) {
+      for (char* p = buf; *p;) {
+        char* e = nullptr;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long z = a;
+        p = e;
+        if (*p == '-') { z = std::strtol(p + 1, &e, 10); p = e; }
+        for (long c = a; c <= z; c++) cpus.push_back((int)c);
+        if (*p == ',') p++;
+      }
+    }
+    std::fclose(f);
+    nodes.push_back(cpus);
+  }
+  return nodes;
+  }();
+  return cached;
+}
+
+
+// NUMA node of a HIP device (from its PCI address: /sys/bus/pci/devices/<id>/numa_node), -1 when the kernel does not say.
+// hipHostMalloc places pinned memory on the node of the CURRENT device whatever thread calls it (scripts/numa_probe.py on the
+// 8-GPU box: a thread bound to node 0 still gets node-1 pages for a GPU on node 1), so pinned blocks are pooled per node and
+// allocated under the device they are for: a multi-GPU call's staging and result blocks then sit next to the GPU that reads /
+// writes them.
+int device_numa_node(int device) {
+  static std::mutex mu;
+  static std::map<int, int> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(device);
+  if (it != cache.end()) return it->second;
+  int node = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+    std::string id(bus);
+    for (char& ch : id) ch = (char)std::tolower((unsigned char)ch);
+    std::ifstream f("/sys/bus/pci/devices/" + id + "/numa_node");
+    if (!(f >> node)) node = -1;
+  } else {
+    (void)hipGetLastError();
+  }
+  cache[device] = node;
+  return node;
+}
+
+// Binds the calling thread to the cpus of `node` (no-op when there is one node, when the node is unknown, or when this thread
+// is bound there already).  RUHVRO_HIP_NUMA_BIND=0 turns it off.
+void bind_thread_to_node(int node) {
+  static const bool on = env_long_early("RUHVRO_HIP_NUMA_BIND", 1, 0, 1) != 0;
+  thread_local int bound = -2;
+  const std::vector<std::vector<int>>& nodes = numa_node_cpus();
+  if (!on || node < 0 || nodes.size() < 2 || (size_t)node >= nodes.size() || bound == node) return;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  for (int c : nodes[(size_t)node]) if (c < CPU_SETSIZE) CPU_SET(c, &set);
+  if (sched_setaffinity(0, sizeof set, &set) == 0) bound = node;
+  else bound = -3;            // (a cpuset that excludes the node: leave the thread where it may run, and do not try again)
 }
 
 unsigned effective_cpus() {
