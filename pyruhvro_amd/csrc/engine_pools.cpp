@@ -3,6 +3,7 @@
 #include "engine_internal.h"
 
 #include <sched.h>
+#include <unistd.h>
 
 #include <cctype>
 #include <map>
@@ -136,14 +137,25 @@ int device_numa_node(int device) {
 // is bound there already).  RUHVRO_HIP_NUMA_BIND=0 turns it off.
 void bind_thread_to_node(int node) {
   static const bool on = env_long_early("RUHVRO_HIP_NUMA_BIND", 1, 0, 1) != 0;
-  thread_local int bound = -2;
+  thread_local int tried = -2;           // the node this thread last asked for (bound there, or found no allowed cpu on it)
   const std::vector<std::vector<int>>& nodes = numa_node_cpus();
-  if (!on || node < 0 || nodes.size() < 2 || (size_t)node >= nodes.size() || bound == node) return;
+  if (!on || node < 0 || nodes.size() < 2 || (size_t)node >= nodes.size() || tried == node) return;
+  tried = node;
+  // only within the cpus the PROCESS was given (taskset / a launcher's binding): the mask of its main thread, read once -- a
+  // thread may set its affinity to cpus outside the mask it inherited, and the engine must not undo the user's restriction
+  static cpu_set_t allowed;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(getpid(), sizeof allowed, &allowed) != 0)
+      for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &allowed);
+  });
   cpu_set_t set;
   CPU_ZERO(&set);
-  for (int c : nodes[(size_t)node]) if (c < CPU_SETSIZE) CPU_SET(c, &set);
-  if (sched_setaffinity(0, sizeof set, &set) == 0) bound = node;
-  else bound = -3;            // (a cpuset that excludes the node: leave the thread where it may run, and do not try again)
+  int cnt = 0;
+  for (int c : nodes[(size_t)node])
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) { CPU_SET(c, &set); cnt++; }
+  if (cnt > 0) (void)sched_setaffinity(0, sizeof set, &set);      // (no allowed cpu on that node: the thread stays where it may run)
 }
 
 unsigned effective_cpus() {
