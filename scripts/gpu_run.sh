@@ -11,7 +11,7 @@
 #   notrust               parity core again with RUHVRO_HIP_NO_TRUST=1
 #   smoke                 __graft_entry__.smoke()
 #   bench[:<args>]        bench.py <args> -> bench.json + a short summary
-#   stats                 rocprofv3 --kernel-trace --stats over the bench's single-stream region -> kernel_stats.txt
+#   stats[:<workload>]    rocprofv3 --kernel-trace --stats over the bench's single-stream region -> kernel_stats_<workload>.txt
 #   stamp                 FETCH_SIZE / WRITE_SIZE passes (separate) -> hbm_traffic.json stamped with the kernel key, copied to profiles/
 #   stamp_encode          the same for the Arrow -> Avro direction -> encode_hbm_traffic.json
 #   pmc[:<workload>]      SQ / TCP / GRBM counter groups, one --pmc pass each
@@ -34,8 +34,10 @@ for step in "$@"; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log;;
     bench) timeout 1200 python bench.py $arg > $OUT/bench_$n.json 2> $OUT/bench_$n.err; echo "bench rc=$?"; tail -2 $OUT/bench_$n.err
            cp $OUT/bench_$n.json $OUT/bench.json; python scripts/bench_summary.py $OUT/bench_$n.json;;
-    stats) timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_stats -o stats -- python bench.py --steps 20 --warmup 5 $B > $OUT/p_stats.log 2>&1; echo "stats rc=$?"
-           summary $OUT/p_stats | grep -vE "^$" > $OUT/kernel_stats.txt; head -9 $OUT/kernel_stats.txt; rm -rf $OUT/p_stats;;
+    stats) W=${arg:-full10m}
+           timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/p_stats -o stats -- python bench.py --workload $W --steps 20 --warmup 5 $B > $OUT/p_stats_$W.log 2>&1; echo "stats rc=$?"
+           grep "^{" $OUT/p_stats_$W.log > $OUT/bench_stats_$W.json
+           summary $OUT/p_stats | grep -vE "^$" > $OUT/kernel_stats_$W.txt; [ "$W" = full10m ] && cp $OUT/kernel_stats_$W.txt $OUT/kernel_stats.txt; head -9 $OUT/kernel_stats_$W.txt; rm -rf $OUT/p_stats;;
     stamp) timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/p_fetch -o fetch -- python bench.py --steps 3 --warmup 2 $B > $OUT/p_fetch.log 2>&1; echo "fetch rc=$?"
            timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/p_write -o write -- python bench.py --steps 3 --warmup 2 $B > $OUT/p_write.log 2>&1; echo "write rc=$?"
            KEY=$(python -c "from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS; print(cabi.kernel_key(SCHEMAS['full']))")
