@@ -127,6 +127,41 @@ KAT_ENUM = {"type": "record", "name": "test", "fields": [
     {"name": "c", "type": {"type": "enum", "name": "suit",
                            "symbols": ["diamonds", "spades", "clubs", "hearts"]}, "default": "spades"}]}
 
+# Round 6: the same record as a production event stream carries it: `created_at` a nullable
+# timestamp-micros at today's epoch (an 8-byte varint behind a branch byte), an `int` of epoch seconds (5 bytes), a
+# snowflake id (9 bytes), a mostly-null free-text column whose tail is > 8 KiB.  generate_avro.py's columns stay as they are.
+FULL_REALISTIC = {"type": "record", "name": "UserEvent", "fields": _USER_COMMON + [
+    {"name": "status", "type": ["null", "string", "int", "boolean"], "default": None},
+    {"name": "created_at", "type": ["null", {"type": "long", "logicalType": "timestamp-micros"}], "default": None},
+    {"name": "class", "type": {"type": "enum", "name": "enum_col", "symbols": ["A", "B", "C"]}},
+    {"name": "login_ts", "type": "int"},
+    {"name": "event_id", "type": "long"},
+    {"name": "note", "type": ["null", "string"], "default": None},
+]}
+
+WIDE_ARRAYS = 12
+
+
+def wide_schema(ncols: int) -> dict:
+    """`ncols` nullable string columns with WIDE_ARRAYS arrays of strings spread between them: ncols + 2 * WIDE_ARRAYS scanned
+    counters (100-300-field event schemas are ordinary; the reference has no width limit,
+    fast_decode.rs:342-370)."""
+    fields = []
+    every = max(ncols // WIDE_ARRAYS, 1)
+    na = 0
+    for i in range(ncols):
+        fields.append({"name": f"c{i}", "type": ["null", "string"], "default": None})
+        if (i + 1) % every == 0 and na < WIDE_ARRAYS:
+            fields.append({"name": f"a{na}", "type": {"type": "array", "items": "string"}})
+            na += 1
+    while na < WIDE_ARRAYS:
+        fields.append({"name": f"a{na}", "type": {"type": "array", "items": "string"}})
+        na += 1
+    return {"type": "record", "name": f"Wide{ncols}", "fields": fields}
+
+
+WIDE_COLS = (97, 200, 400)
+
 SCHEMAS = {k: json.dumps(v) for k, v in {
     "full": FULL, "flat4": FLAT4, "cfg3": CFG3,
     "flat_primitives": FLAT_PRIMITIVES, "nullable_primitives": NULLABLE_PRIMITIVES,
@@ -134,5 +169,7 @@ SCHEMAS = {k: json.dumps(v) for k, v in {
     "t_nullable": T_NULLABLE, "t_logical": T_LOGICAL, "t_enum": T_ENUM, "t_nested": T_NESTED,
     "t_nullable_nested": T_NULLABLE_NESTED, "t_union": T_UNION, "t_array_str": T_ARRAY_STR,
     "t_array_int": T_ARRAY_INT, "t_map_str": T_MAP_STR,
+    "full_realistic": FULL_REALISTIC, "full_realistic_heavy": FULL_REALISTIC, "full_skewed": FULL,
+    **{f"wide{n}": wide_schema(n) for n in WIDE_COLS},
     "kat_user": KAT_USER, "kat_userdata": KAT_USERDATA, "kat_addresses": KAT_ADDRESSES, "kat_enum": KAT_ENUM,
 }.items()}

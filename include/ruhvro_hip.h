@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RH_ABI_VERSION 6
+#define RH_ABI_VERSION 7
 
 /* error classes (return codes) */
 #define RH_OK 0
@@ -260,7 +260,15 @@ enum {
   RH_CTR_SINGLE_PASS_CALLS = 6, /* decode calls that took the single-pass form (one kernel sizes, scans across tiles and emits) */
   RH_CTR_SINGLE_PASS_FAILOVERS = 7, /* ... of which outgrew a column capacity and were repeated on the two-pass form */
   RH_CTR_BACKGROUND_COMPILES = 8, /* kernel compile jobs started behind a call that went ahead on the generic kernels (ABI 6) */
-  RH_CTR_COUNT = 9
+  /* ABI 7: what the walks met, summed over the tiles of every single-submission call by its last kernel (rh_k_publish reads the
+   * size pass's per-tile flags; a call's first run on a schema and a call repeated with an exact arena are not counted).  A tile
+   * is one workgroup's records (256, or 64 for wide schemas); all of these are 0 on input that stays inside the fast wire forms. */
+  RH_CTR_TILES = 9,             /* tiles of the calls counted below                                                           */
+  RH_CTR_CAREFUL_TILES = 10,    /* tiles the emit pass walked with the careful form (an anomaly in the size pass, or no window)  */
+  RH_CTR_OVER_WINDOW_TILES = 11, /* tiles whose bytes did not fit the LDS window in one piece                                  */
+  RH_CTR_REWALKED_WAVES = 12,   /* wavefronts the size pass walked twice (a record outside the fast wire forms, or malformed)  */
+  RH_CTR_SUBTILED_TILES = 13,   /* over-window tiles that were staged through the window in record ranges (not walked from HBM) */
+  RH_CTR_COUNT = 14
 };
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 

@@ -141,7 +141,8 @@ def lib():
     return _lib
 
 
-ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers", "background_compiles")
+ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers", "background_compiles",
+                   "tiles", "careful_tiles", "over_window_tiles", "rewalked_waves", "subtiled_tiles")
 
 
 def engine_counters() -> dict:

@@ -33,7 +33,7 @@ struct rh_decode_call {
   const SpecKernel* sk = nullptr;
   uint64_t narrow_rows = 0, tile = 0, bpc64 = 0, payload = 0;
   uint32_t nblocks = 0;
-  uint64_t o_null = 0, o_tot = 32, ctrl_bytes = 0;
+  uint64_t o_null = 0, o_tot = 48, ctrl_bytes = 0;
   uint32_t null_slots = rh::kNullSlots;      // program.h null_slots_for(k)
   Lease ws, hctrl, dtab, prof_buf;
   std::unique_ptr<CtrlLease> ctrl;
@@ -241,7 +241,7 @@ struct rh_decode_call {
       if (token == 0) token = next_token.fetch_add(1);
       o_flag_h = align_up(o_null + 4ull * nnodes * k, 8);
       *(volatile uint32_t*)(hctrl.ptr() + o_flag_h) = 0;
-      if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, stream))
+      if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, P.tileflag, 0u /* no size pass: nobody wrote the tile flags */, 8u, stream))
         throw HipError("k_publish launch failed");
       ctrl->b.clean = true;
       published = true;
@@ -311,7 +311,7 @@ struct rh_decode_call {
 
     // ---- control block: [first_bad u64 | layout flag, ticket | arena bytes | pad][totals u64 K*k][nullcount u32 nnodes*k*null_slots]
     //      workspace: errinfo | blocksum | blockbase | tileflag | lanecnt
-    o_tot = 32;      // control words first (program.h): first_bad, layout flag, arena bytes used
+    o_tot = 48;      // control words first (program.h): first_bad, layout flag, arena bytes used, pad; words 8..11 = the tile statistics rh_k_publish sums
     o_tick = o_tot + 8ull * K * k;                    // [k] tile tickets of the single-pass form (zero like the rest of the block)
     o_null = align_up(o_tick + 4ull * k, 16);
     null_slots = rh::null_slots_for(k);
@@ -322,7 +322,7 @@ struct rh_decode_call {
     const uint64_t o_bsum = align_up(o_err + sizeof(rh::ErrInfo) * (uint64_t)nblocks, kAlign);
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
     const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
-    const uint64_t o_lcnt = align_up(o_flag + (sk ? 4ull * nblocks : 0), kAlign);
+    const uint64_t o_lcnt = align_up(o_flag + 4ull * nblocks, kAlign);
     const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((K + 1) / 2) * nblocks * tile : 0), kAlign);
     hp.mark("setup");
     ws = Lease(dev_pool(), ws_bytes, device);
@@ -369,6 +369,11 @@ struct rh_decode_call {
         const uint64_t step = (160 * 1024 / nwg) & ~511ull;
         if (lds_fixed + win > step && step > lds_fixed && step - lds_fixed >= min_win) { win = (step - lds_fixed) & ~15ull; break; }
       }
+    }
+    // (RUHVRO_HIP_WIN_BYTES: the window as given -- 0 = none, every tile is walked from global memory; measurement knob)
+    {
+      const long fixed_win = env_long("RUHVRO_HIP_WIN_BYTES", -1, 0, 150 * 1024);
+      if (fixed_win >= 0) win = std::min<uint64_t>((uint64_t)fixed_win & ~15ull, (lds_cap - lds_fixed) & ~15ull);
     }
     P.win_bytes = (uint32_t)win;
     lds_bytes = lds_fixed + (uint32_t)win;
@@ -451,7 +456,7 @@ struct rh_decode_call {
         if (token == 0) token = next_token.fetch_add(1);
         o_flag_h = align_up(o_null + 4ull * nnodes * k, 8);                 // host layout: head | compact null counts | token
         *(volatile uint32_t*)(hctrl.ptr() + o_flag_h) = 0;
-        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, stream))
+        if (rh_launch_publish(ctrl->ptr(), hdev, (uint32_t)(o_null / 4), (uint32_t)(nnodes * (int)k), (uint32_t)(o_flag_h / 4), token, null_slots, P.tileflag, (K > 0 && n > 0) ? nblocks : 0u, 8u, stream))
           throw HipError("k_publish launch failed");
         ctrl->b.clean = true;
         published = true;
@@ -493,6 +498,12 @@ struct rh_decode_call {
       }
       hp.mark("sync");
       check_bad(hctrl.ptr());
+      if (published && K > 0 && n > 0 && !single) {      // the tile statistics rh_k_publish summed (include/ruhvro_hip.h RH_CTR_*_TILES)
+        const uint32_t* stw = (const uint32_t*)(hctrl.ptr() + 32);
+        count(RH_CTR_TILES, nblocks);
+        count(RH_CTR_CAREFUL_TILES, stw[0]); count(RH_CTR_OVER_WINDOW_TILES, stw[1]);
+        count(RH_CTR_REWALKED_WAVES, stw[2]); count(RH_CTR_SUBTILED_TILES, stw[3]);
+      }
       if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
       const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
       if (single) {

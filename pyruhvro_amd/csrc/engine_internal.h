@@ -51,7 +51,8 @@ int rh_launch_scan(const rh::KParams* P, void* stream, void* start, void* stop);
 int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, const rh::BufDesc* desc, uint32_t nbuf, uint32_t k,
                    const unsigned long long* ctrl, void* stream);
 int rh_launch_layout(const rh::LParams* L, void* stream);
-int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots, void* stream);
+int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots,
+                      const uint32_t* tileflag, uint32_t nflags, uint32_t stat_word, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
 uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
@@ -79,7 +80,7 @@ struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic ker
 struct NeedTwoPass {};     // the single-pass form outgrew a column capacity (or needs what only the two-pass layout checks): repeat
 
 extern std::atomic<uint64_t> g_counters[RH_CTR_COUNT];     // rh_engine_counters (include/ruhvro_hip.h)
-inline void count(int which) { g_counters[which].fetch_add(1, std::memory_order_relaxed); }
+inline void count(int which, uint64_t by = 1) { g_counters[which].fetch_add(by, std::memory_order_relaxed); }
 
 #define HIPCHK(expr)                                                                          \
   do {                                                                                        \

@@ -191,6 +191,7 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) {
     if (lane == 0) s.wtot[k * 4 + wave] = v;
   }
   report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot
+  if (tid == 0) P.tileflag[blockIdx.x] = fits ? 0u : (uint32_t)TF_OVER_WINDOW;      // (statistics only: this form always walks carefully)
   if ((int)tid < P.K)
     P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
         s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
@@ -362,11 +363,28 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_scan_layout(KParams P,
 // barrier): the host spins on that word in its pinned block instead of waiting for a stream event -- an event record
 // between two calls cost the GPU 5.7 us of idle time per call (profiles/r03aj_timeline.txt), and the spin sees the
 // token ~3 us sooner than hipStreamSynchronize returns (tools/synclat.hip).
+// ABI 7: the size pass's per-tile flags (program.h TileFlag) are summed here into four words of the head -- what
+// rh_engine_counters reports as careful / over-window / sub-tiled tiles and re-walked wavefronts (nflags = 0: no size pass ran).
 extern "C" __global__ void __launch_bounds__(kBlock) rh_k_publish(uint32_t* ctrl, uint32_t* host, uint32_t head_words,
-                                                                 uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots) {
+                                                                 uint32_t null_entries, uint32_t flag_word, uint32_t token, uint32_t nslots,
+                                                                 const uint32_t* tileflag, uint32_t nflags, uint32_t stat_word) {
+  __shared__ uint32_t stat[4];
+  if (threadIdx.x < 4) stat[threadIdx.x] = 0;
+  __syncthreads();
   for (uint32_t i = threadIdx.x; i < head_words; i += kBlock) {      // control words + chunk totals, as they are
     host[i] = ctrl[i];
     ctrl[i] = 0;
+  }
+  if (nflags) {
+    uint32_t car = 0, over = 0, sub = 0, rew = 0;
+    for (uint32_t i = threadIdx.x; i < nflags; i += kBlock) {
+      const uint32_t f = tileflag[i];
+      car += (f >> 1) & 1u; over += (f >> 2) & 1u; sub += (f >> 3) & 1u; rew += (f >> 8) & 0xFFu;
+    }
+    car = wave_sum(car); over = wave_sum(over); sub = wave_sum(sub); rew = wave_sum(rew);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[0], car); atomicAdd(&stat[1], over); atomicAdd(&stat[2], rew); atomicAdd(&stat[3], sub); }
+    __syncthreads();
+    if (threadIdx.x < 4) host[stat_word + threadIdx.x] = stat[threadIdx.x];
   }
   uint32_t* slots = ctrl + head_words;                               // [null_entries][nslots] (program.h null_slots_for)
   for (uint32_t e = threadIdx.x; e < null_entries; e += kBlock) {
@@ -500,10 +518,10 @@ extern "C" int rh_launch_init(void* const* bufptr, const uint64_t* bufsize, cons
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null_entries, uint32_t flag_word, uint32_t token,
-                                 uint32_t nslots, void* stream) {
+                                 uint32_t nslots, const uint32_t* tileflag, uint32_t nflags, uint32_t stat_word, void* stream) {
   (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
   hipLaunchKernelGGL(rh::rh_k_publish, dim3(1), dim3(rh::kBlock), 0, (hipStream_t)stream, (uint32_t*)ctrl, (uint32_t*)host, head_words,
-                     null_entries, flag_word, token, nslots);
+                     null_entries, flag_word, token, nslots, tileflag, nflags, stat_word);
   return (int)hipGetLastError();
 }
 extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {

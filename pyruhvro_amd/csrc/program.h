@@ -149,6 +149,15 @@ enum LayoutFlag : uint32_t {
   LF_NEED_WIDE = 4,    // a child row domain reaches 2^28 rows: only the generic kernels index that far
 };
 
+// Per-tile word the size pass leaves for the emit pass (KParams::tileflag) and for the call's statistics (rh_k_publish)
+enum TileFlag : uint32_t {
+  TF_SATURATED = 1,     // a per-record counter does not fit its 16-bit hand-over slot: the emit pass sizes the tile again
+  TF_CAREFUL = 2,       // the emit pass walks this tile with the careful form
+  TF_OVER_WINDOW = 4,   // the tile's bytes do not fit the LDS window in one piece
+  TF_SUBTILED = 8,      // ... and were staged through it in record ranges
+  TF_REWALK_ONE = 256,  // bits 8..15: wavefronts the size pass walked twice
+};
+
 // Parameters of rh_k_layout (one workgroup): exact arena layout on the device from the scanned totals, so that a
 // call is ONE stream submission (k_size -> k_scan -> k_layout -> k_init -> k_emit) with no host round trip in between.
 struct LParams {
@@ -200,7 +209,7 @@ struct KParams {
   uint32_t* nullcount;       // [nnodes][k][null_slots]: a workgroup adds into slot (tile & (null_slots - 1)); rh_k_publish / the host sum the slots
   // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
   uint32_t* lanecnt;         // [nblocks*TILE][ceil(K/2)] per-record counters, 16 bits each (saturated at 0xFFFF), record-major
-  uint32_t* tileflag;        // [nblocks] bit 0 = a counter of this tile saturated: k_emit re-runs the size walk; bit 1 = walk this tile carefully
+  uint32_t* tileflag;        // [nblocks] TileFlag bits
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
   // single-pass form (spec_body.h spec_fused): one launch sizes, scans (decoupled look-back over the tiles of a chunk) and emits
   unsigned long long* lookback;   // [nblocks][K] tile state words: bits 63..62 = 1 tile total / 2 inclusive prefix, low 32 bits = value; zero = not there yet

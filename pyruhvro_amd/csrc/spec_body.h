@@ -235,7 +235,7 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
     for (;;) {
       const bool need = inlist && rm == 0;                   // at a block boundary: count, or the 0 terminator
       uint32_t raw, n;
-      (void)varint16(src.ld4(L.cur), 4u, raw, n);
+      (void)varint24(src.ld4(L.cur), 4u, raw, n);
       if (need) {
         L.cur += n;
         if ((raw >> 1) == 0) inlist = false;
@@ -344,9 +344,11 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   RH_MARK(17);
   spec_run_walk<S, false, false>(P, c, s.win, L, fits, wb16);
   bool careful = !fits;
+  uint32_t tflag = fits ? 0u : (uint32_t)TF_OVER_WINDOW;
   L.redo = L.redo || L.cur > L.end;      // the one bounds check of the fast walk (walk.h read_head): a cursor past its record's end
   if (__any(L.redo)) {   // some record of this wave left the fast wire forms (or is malformed): walk the wave again, carefully
     careful = true;
+    tflag |= (uint32_t)TF_REWALK_ONE;
     spec_ctx_init(c, P, s, g, tid);
     lane_init_from(L, g, o0, o1, wb16, tid);
     if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
@@ -387,7 +389,11 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   }
   if constexpr (S::K > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const bool anysat = __any(sat);
-  if (lane == 0 && (anysat || careful)) atomicOr(&s.misc[2], (anysat ? 1u : 0u) | (careful ? 2u : 0u));
+  // (TileFlag: the re-walk count is ADDED, one per wavefront; the other bits are the same for every wavefront that sets them)
+  if (lane == 0 && (anysat || careful)) {
+    atomicOr(&s.misc[2], (anysat ? (uint32_t)TF_SATURATED : 0u) | (careful ? (uint32_t)TF_CAREFUL : 0u) | (tflag & (uint32_t)TF_OVER_WINDOW));
+    if (tflag & (uint32_t)TF_REWALK_ONE) atomicAdd(&s.misc[2], (uint32_t)TF_REWALK_ONE);
+  }
   report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
   if (tid == 0) P.tileflag[tile] = s.misc[2];
   for (int k = tid; k < S::K; k += T) {

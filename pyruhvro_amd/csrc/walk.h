@@ -73,6 +73,14 @@ struct LdsSrc {
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     return ((uint64_t)hi << 32) | lo;
   }
+  // 12 bytes at any byte position (a branch byte + a 10-byte varint): four aligned dwords (two ds_read2_b32), three v_alignbyte
+  __device__ __forceinline__ void ld12(uint32_t p, uint64_t& lo, uint32_t& hi) const {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3];
+    const uint32_t sh = p & 3u;
+    lo = ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbyte(d3, d2, sh);
+  }
   // 16 bytes at any byte position: five aligned dwords, four v_alignbyte
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
@@ -125,6 +133,13 @@ struct LdsAbsSrc {
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
     return ((uint64_t)hi << 32) | lo;
   }
+  __device__ __forceinline__ void ld12(uint32_t p, uint64_t& lo, uint32_t& hi) const {
+    const RH_LDS uint32_t* a = dw(p);
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3];
+    const uint32_t sh = p & 3u;
+    lo = ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbyte(d3, d2, sh);
+  }
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
     const RH_LDS uint32_t* a = dw(p);
     const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
@@ -167,6 +182,12 @@ struct GlobalSrc {
   }
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
   __device__ __forceinline__ uint32_t ld4(uint32_t p) const { return (uint32_t)ld8(p); }
+  __device__ __forceinline__ void ld12(uint32_t p, uint64_t& lo, uint32_t& hi) const {
+    if ((uint64_t)p + 12 <= lim) { lo = *reinterpret_cast<const u64u*>(g + p); hi = *reinterpret_cast<const u32u*>(g + p + 8); return; }
+    lo = ld8(p);
+    hi = 0;
+    for (uint32_t j = 8; j < 12 && (uint64_t)p + j < lim; j++) hi |= (uint32_t)g[p + j] << (8 * (j - 8));
+  }
   // (copy8_pieces over global memory: unaligned reads are fine here, so the "aligned dwords" are taken as if p & 3 were 0
   //  -- the pieces' funnel shift is by p & 3, which callers of a GlobalSrc get right by reading at p - (p & 3))
   __device__ __forceinline__ uint32_t ld4a(uint32_t p) const { return (uint32_t)ld8(p & ~3u); }
@@ -415,21 +436,43 @@ __device__ __forceinline__ uint32_t rd_varint_slow(const Src& src, uint32_t& cur
   return E_OK;
 }
 
-// zig-zag LEB128 varint of <= 4 bytes at bit 0 of y: raw (pre-zigzag) 28-bit value and byte length.
-__device__ __forceinline__ bool varint32(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
-  const uint32_t t = ~y & 0x80808080u;            // bit 7 of every byte WITHOUT a continuation flag
-  n = (uint32_t)(__ffs((int)t) + 7) >> 3;         // 1..4, 0 when all four bytes continue
-  y &= t ^ (t - 1);                               // keep bytes 0..n-1
-  y = ((y & 0x7F007F00u) >> 1) | (y & 0x007F007Fu);
-  raw = ((y & 0x3FFF0000u) >> 2) | (y & 0x00003FFFu);
-  return t != 0 && n <= avail;
+// The single-read wire forms of the fast walk (round 6: sized for what production data carries, not for the benchmark
+// generator -- VERDICT round 5, item 2; the reference's read_zigzag_long, fast_decode.rs:854-869, costs the same for any length):
+//   int                       <= 5 bytes  (every i32; longer encodings of an int are legal and take the careful form)
+//   long                      <= 10 bytes (every i64, behind a branch byte too: timestamps in microseconds, snowflake ids)
+//   string / bytes length,
+//   array / map block count   <= 3 bytes  (below 2^20: 1 MiB, a million items)
+//   union / enum index        <= 2 bytes
+// Anything else -- padded encodings beyond these widths, an 11th byte, a varint running past the record -- is an anomaly.
+
+// zig-zag varint of <= 5 bytes at bit 0 of y (>= 5 valid bytes), decoded and truncated the way the reference's `as i32`
+// truncates (fast_decode.rs:424,430): bits 33 and 34 of a 5-byte encoding never reach the value.
+__device__ __forceinline__ bool varint35(uint64_t y, uint32_t avail, uint32_t& v32, uint32_t& n) {
+  uint32_t lo = (uint32_t)y;
+  const uint32_t b4 = (uint32_t)(y >> 32) & 0xFFu;
+  const uint32_t t = ~lo & 0x80808080u;            // bit 7 of every byte WITHOUT a continuation flag
+  const bool ext = t == 0;                         // four continuation bytes: the fifth byte ends the varint
+  n = ext ? 5u : (uint32_t)(__ffs((int)t) + 7) >> 3;
+  lo &= t ^ (t - 1);                               // keep bytes 0..n-1 (all four when ext: 0 ^ 0xFFFFFFFF)
+  lo = ((lo & 0x7F007F00u) >> 1) | (lo & 0x007F007Fu);
+  uint32_t raw = ((lo & 0x3FFF0000u) >> 2) | (lo & 0x00003FFFu);
+  const uint32_t e4 = ext ? b4 : 0u;
+  raw |= e4 << 28;                                 // raw bits 28..31
+  v32 = ((raw >> 1) | ((e4 & 0x10u) << 27)) ^ (0u - (raw & 1u));      // raw bit 32 -> value bit 31
+  return (e4 & 0x80u) == 0 && n <= avail;
 }
 
-// The varints that are small in practice -- string lengths, union / enum indices, block counts -- take a two-byte
-// form on the fast walk: raw value (14 bits) and byte length of a varint of <= 2 bytes at bit 0 of y.  Longer ones
-// (a string of 8 KiB and more, ...) are an anomaly there and go to the careful walk, like any other wire form
-// outside the single-read path.
-// (k_size 0.375 -> 0.358 ms on the full schema, profiles/r02d_variants_ab.txt; the size pass is VALU-issue bound.)
+// length / block count: raw (pre-zigzag) value and byte length of a varint of <= 3 bytes at bit 0 of y
+__device__ __forceinline__ bool varint24(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
+  const uint32_t m0 = (uint32_t)((int32_t)(y << 24) >> 31);          // all ones when byte 0 carries a continuation flag
+  const uint32_t m1 = (uint32_t)((int32_t)(y << 16) >> 31) & m0;     // ... and byte 1 too
+  raw = (y & 0x7Fu) | ((((y >> 8) & 0x7Fu) & m0) << 7) | ((((y >> 16) & 0x7Fu) & m1) << 14);
+  n = 1u - m0 - m1;                                                  // 1, 2 or 3
+  return (y & 0x808080u) != 0x808080u && n <= avail;
+}
+
+// union / enum index: the same for <= 2 bytes
+// (k_size 0.375 -> 0.358 ms on the full schema against the 4-byte form, profiles/r02d_variants_ab.txt; the size pass is VALU-issue bound.)
 constexpr bool kNarrow = true;
 __device__ __forceinline__ bool varint16(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
   const uint32_t m = (uint32_t)((int32_t)(y << 24) >> 31);     // all ones when byte 0 carries a continuation flag
@@ -438,7 +481,7 @@ __device__ __forceinline__ bool varint16(uint32_t y, uint32_t avail, uint32_t& r
   return (y & 0x8080u) != 0x8080u && n <= avail;
 }
 
-// same for <= nx (<= 8) bytes at bit 0 of x, full 64-bit value
+// zig-zag varint of <= 8 bytes at bit 0 of x, full 64-bit value (the careful walk's first try: rd_varint)
 __device__ __forceinline__ bool varint64(uint64_t x, uint32_t nx, uint32_t avail, int64_t& out, uint32_t& n) {
   const uint64_t t = ~x & 0x8080808080808080ull;
   if (t == 0) return false;
@@ -450,6 +493,26 @@ __device__ __forceinline__ bool varint64(uint64_t x, uint32_t nx, uint32_t avail
   x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
   out = (int64_t)(x >> 1) ^ -(int64_t)(x & 1);
   return true;
+}
+
+// zig-zag varint of <= 10 bytes, branch-free: bytes 0..7 in lo, bytes 8..9 in the low half of hi.  The tenth byte's payload
+// is shifted by 63: only its bit 0 reaches the value, as in the reference (fast_decode.rs:859: `<< shift` drops the rest).
+__device__ __forceinline__ bool varint64x(uint64_t lo, uint32_t hi, uint32_t avail, int64_t& out, uint32_t& n) {
+  const uint64_t t = ~lo & 0x8080808080808080ull;
+  const bool ext = t == 0;                          // eight continuation bytes
+  const uint32_t th = ~hi & 0x8080u;
+  const uint32_t nl = ((uint32_t)__builtin_ctzll(t | (1ull << 63)) >> 3) + 1;      // 1..8
+  const uint32_t nh = ((uint32_t)__builtin_ctz(th | 0x8000u) >> 3) + 1;            // 1..2
+  n = ext ? 8u + nh : nl;
+  uint64_t x = lo & (t ^ (t - 1));                  // bytes 0..n-1 (all eight when ext)
+  x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
+  x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
+  x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
+  const uint64_t e8 = ext ? (uint64_t)(hi & 0x7Fu) : 0ull;
+  const uint64_t e9 = (ext && nh == 2u) ? (uint64_t)((hi >> 8) & 1u) : 0ull;
+  x |= (e8 << 56) | (e9 << 63);
+  out = (int64_t)(x >> 1) ^ -(int64_t)(x & 1);
+  return (!ext || th != 0) && n <= avail;
 }
 
 template <class Src>
@@ -489,15 +552,18 @@ __device__ __forceinline__ bool read_head_slow(const Src& src, Lane& L, bool nul
 // in the fast walks (a careful walk may re-read a head byte by byte and would leave L.la stale).
 template <bool CAREFUL, bool TRUST = false, int LA = 0, class Src>
 __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, bool nullable, bool null_first, bool want_varint,
-                                         bool wide, int64_t& v, bool small = false) {
+                                         bool wide, int64_t& v, int small = 0) {
   if (!nullable && !want_varint) return dec;
   static_assert(LA == 0 || !CAREFUL, "head fusion is for the fast walks");
-  const bool narrow = kNarrow && small && !wide;      // `small`: a length / index / count (see varint16)
+  // `small`: 1 = a union / enum index (varint16), 2 = a length / block count (varint24); 0 = a value (int: varint35, long: varint64x)
+  const bool narrow = kNarrow && small != 0 && !wide;
   uint64_t x;
+  uint32_t xh = 0;                                    // bytes 8..11 behind the cursor (a long only)
   if constexpr ((LA & 1) != 0) x = L.la;
   else if constexpr ((LA & 2) != 0 && (LA >> 2) == 8) x = src.ld8(L.cur);
   else if constexpr ((LA & 2) != 0) x = (uint64_t)src.ld4(L.cur);
-  else x = (want_varint && wide) ? src.ld8(L.cur) : (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
+  else if (want_varint && wide) src.ld12(L.cur, x, xh);
+  else x = (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : nullable ? src.ld8(L.cur) : src.ld5(L.cur);
   // The fast size walk (neither careful nor trusted) checks a record's bounds ONCE, at its end (spec_size: cursor past
   // the record's end -> the wave is walked again, carefully): a cursor only ever moves forward, so a read that runs past
   // the end leaves it past the end for good, and what such a lane decodes meanwhile is never used.  No compare against
@@ -519,11 +585,11 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   if (want_varint) {
     const uint32_t av = avail - skip;               // wraps only when okb is false
     if (wide) {
-      okv = varint64(y, nullable ? 7 : 8, av, v, n);
-    } else {
+      okv = varint64x(nullable ? (y | ((uint64_t)xh << 56)) : x, nullable ? xh >> 8 : xh, av, v, n);
+    } else if (narrow) {
       uint32_t raw;
-      okv = narrow ? varint16((uint32_t)y, av, raw, n) : varint32((uint32_t)y, av, raw, n);
-      if (narrow && !CAREFUL) {
+      okv = small == 2 ? varint24((uint32_t)y, av, raw, n) : varint16((uint32_t)y, av, raw, n);
+      if (!CAREFUL) {
         // a length / index / count is never negative in a well-formed record: on the fast walk the sign bit of the
         // zig-zag form is one more anomaly (the careful walk raises the reference's error for it) and the value is
         // just raw >> 1 -- no zig-zag decode, no sign tests downstream (~3 VALU per varint, ~17 of them per record)
@@ -532,6 +598,10 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
       } else {
         v = (int64_t)(int32_t)((raw >> 1) ^ (0u - (raw & 1u)));
       }
+    } else {
+      uint32_t v32;
+      okv = varint35(y, av, v32, n);
+      v = (int64_t)(int32_t)v32;
     }
   }
   const bool slow = dec && (!okb || (isval && !okv));
@@ -682,7 +752,7 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
   // latency runs beside the LDS read instead of in front of each store (k_emit -1.2 %, profiles/r03at_variants_ab.txt)
   void* const pb1 = EMIT ? c.buf(op.buf1) : nullptr;
   void* const pb2 = EMIT ? c.buf(op.buf2) : nullptr;
-  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, true);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, true, false, v, op.code == OP_STRING ? 2 : 1);
   const bool want = isval && L.live;
   uint32_t len = 0, spos = 0;
   bool sym_imm = false;
@@ -772,7 +842,7 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
   const bool has_len = op.a == BN_DEC_BYTES || op.a == BN_UUID_STR;
   const uint32_t W = (uint32_t)op.c;
   int64_t v = 0;
-  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, has_len, false, v, true);
+  const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, has_len, false, v, 2);
   const bool want = isval && L.live;
   uint32_t len = (uint32_t)op.b;
   if (has_len) {
@@ -885,7 +955,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   const bool dec = act && L.pres;
   int64_t idx = 0;
   void* const pu1 = EMIT ? c.buf(op.buf1) : nullptr;           // requested ahead of the head: see h_string
-  const bool got = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, false, false, true, false, idx, true) && L.live;
+  const bool got = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, false, false, true, false, idx, 1) && L.live;
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
@@ -955,8 +1025,7 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
   if (TRUST) {               // every block header of this tile took the one-read form below in the size pass, unclamped
     uint32_t raw, n;
-    if (kNarrow) (void)varint16(src.ld4(L.cur), 4u, raw, n);
-    else (void)varint32((uint32_t)src.ld5(L.cur), 4u, raw, n);
+    (void)varint24(src.ld4(L.cur), 4u, raw, n);
     if (need) {
       L.cur += n;
       if ((raw >> 1) == 0) L.live = false;
@@ -967,13 +1036,13 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
     return true;
   }
   // common wire form: a small positive count, or the 0 terminator, in one byte..four bytes
-  const uint32_t x = kNarrow ? src.ld4(L.cur) : (uint32_t)src.ld5(L.cur);
+  const uint32_t x = src.ld4(L.cur);
   uint32_t raw, n;
   // bytes left, 0 for a cursor that is already past its record's end (only the fast walk can be: read_head): such a
   // lane fails here, so a garbage block count never starts a loop
   const int32_t left = (int32_t)(L.end - L.cur);
   const uint32_t lav = CAREFUL ? (uint32_t)left : (uint32_t)(left < 0 ? 0 : left);
-  const bool okv = kNarrow ? varint16(x, lav, raw, n) : varint32(x, lav, raw, n);
+  const bool okv = varint24(x, lav, raw, n);
   const bool fast = need && okv && (raw & 1u) == 0 && (op.buf2 > 0 || raw == 0);   // non-negative; zero-width items take the exact path
   const bool slow = need && !fast;
   if (fast) {

@@ -142,7 +142,7 @@ _FIXED = {pa.int32(): np.int32, pa.int64(): np.int64, pa.float32(): np.float32, 
 def _value_dtype(t: pa.DataType):
     if t in _FIXED:
         return _FIXED[t]
-    if pa.types.is_timestamp(t) or pa.types.is_time64(t):
+    if pa.types.is_timestamp(t) or pa.types.is_time64(t) or pa.types.is_duration(t):
         return np.int64
     if pa.types.is_time32(t):
         return np.int32
@@ -201,7 +201,15 @@ class _Hip:
     def get(cls):
         if cls._lib is None:
             cabi.lib()
-            L = C.CDLL("libamdhip64.so.7")
+            L = None
+            for so in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):      # (the soname list of rtc_compile.cpp)
+                try:
+                    L = C.CDLL(so)
+                    break
+                except OSError:
+                    continue
+            if L is None:
+                raise RuntimeError("the HIP runtime (libamdhip64.so) is not loadable")
             L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
             L.hipFree.argtypes = [C.c_void_p]
             L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

@@ -126,3 +126,25 @@ def test_device_resident_input_and_errors(decoded):
         P.deserialize_to_device(bad, SCHEMAS["full"], 2)
     with pytest.raises(ValueError):
         P.deserialize_to_device(recs[:10], '{"type": "record", "name": "x", "fields": [{"name": "a", "type": "bytes_"}]}', 1)
+
+
+def test_duration_columns_are_int64_views():
+    """An Avro duration (Arrow Duration(ms), schema.cpp format `tDm`) is an int64 buffer like a timestamp: the device view hands it
+    out as such, top level, nullable, and as a list item (`_value_dtype` had no case for it)."""
+    import test_n4_types as N4
+    from oracle import py_walker
+    recs = N4._dur_records(300)
+    exp = py_walker.decode(recs, N4.DUR_SCHEMA, extended=True)
+    dec = P.deserialize_to_device(recs, N4.DUR_SCHEMA, 1)
+    b = dec.batches[0]
+    for name in ("d", "nd"):
+        col = b.column(name)
+        assert col.type == pa.duration("ms")
+        t = torch.from_dlpack(col.values)
+        assert t.dtype == torch.int64 and t.numel() == 300
+        assert t.cpu().tolist() == exp.column(name).cast(pa.int64()).fill_null(0).to_pylist()
+    item = b.column("arr").children[0]
+    assert item.type == pa.duration("ms")
+    assert torch.from_dlpack(item.values).cpu().tolist() == exp.column("arr").values.cast(pa.int64()).to_pylist()
+    for g in dec.to_host():
+        assert_batches_identical(g, exp)

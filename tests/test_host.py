@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(cabi.LIB_PATH)
     for n in sorted(names):
         assert hasattr(lib, n), f"libruhvro_hip.so does not export {n}"
-    assert cabi.lib().rh_abi_version() == 6
+    assert cabi.lib().rh_abi_version() == 7
 
 
 def test_gather_pool_hands_out_every_task_exactly_once():

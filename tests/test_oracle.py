@@ -205,3 +205,7 @@ def test_fastgen_matches_python_spec():
         assert fastgen.split(d, o) == synth.records(name, 3000, seed=5, start=17)
         d1, o1 = fastgen.generate(name, 3000, seed=5, start=17, nthreads=1)
         assert np.array_equal(d, d1) and np.array_equal(o, o1)
+    # round 6: the workloads off the friendly distribution (long varints, 8 KiB strings, > 8,191-item arrays, record-size skew, wide records)
+    for name, n in (("full_realistic", 1500), ("full_realistic_heavy", 120), ("full_skewed", 1500), ("wide97", 200), ("wide200", 120), ("wide400", 60)):
+        d, o = fastgen.generate(name, n, seed=5, start=17, nthreads=3)
+        assert fastgen.split(d, o) == synth.records(name, n, seed=5, start=17), name
