@@ -268,7 +268,8 @@ enum {
   RH_CTR_OVER_WINDOW_TILES = 11, /* tiles whose bytes did not fit the LDS window in one piece                                  */
   RH_CTR_REWALKED_WAVES = 12,   /* wavefronts the size pass walked twice (a record outside the fast wire forms, or malformed)  */
   RH_CTR_SUBTILED_TILES = 13,   /* over-window tiles that were staged through the window in record ranges (not walked from HBM) */
-  RH_CTR_COUNT = 14
+  RH_CTR_RANGED_RETRIES = 14,   /* calls repeated on the generic kernels: a tile past the window met specialised kernels whose ranged pair was not loaded yet */
+  RH_CTR_COUNT = 15
 };
 uint32_t rh_engine_counters(uint64_t* out, uint32_t n);
 

@@ -142,7 +142,7 @@ def lib():
 
 
 ENGINE_COUNTERS = ("fused_calls", "two_sync_calls", "capacity_retries", "wide_fallbacks", "offset32_errors", "split_calls", "single_pass_calls", "single_pass_failovers", "background_compiles",
-                   "tiles", "careful_tiles", "over_window_tiles", "rewalked_waves", "subtiled_tiles")
+                   "tiles", "careful_tiles", "over_window_tiles", "rewalked_waves", "subtiled_tiles", "ranged_retries")
 
 
 def engine_counters() -> dict:

@@ -253,8 +253,12 @@ int rh_schema_prebuild(const rh_schema* s, int* cached, char** err) {
     // every kernel of the schema, each its own compile job, side by side (kernel_jobs.h); waits for all of them
     // (RUHVRO_HIP_PREBUILD_FUSED=0: without the opt-in single-pass kernel -- the most expensive of the five, compiled on its first
     //  use otherwise; build() warms the cache that way for the schemas no single-pass test or bench line uses)
+    // (RUHVRO_HIP_PREBUILD_RANGED=0: likewise without the ranged pair -- the kernels of the tiles past the LDS window, compiled when
+    //  a schema first meets such tiles otherwise)
     const bool fused = env_long("RUHVRO_HIP_PREBUILD_FUSED", 1, 0, 1) != 0;
-    const unsigned parts = (rh::kDecodeParts & ~(fused ? 0u : (1u << rh::KP_FUSED))) | (s->cs->encode_unsupported.empty() ? rh::kEncodeParts : 0u);
+    const bool ranged = env_long("RUHVRO_HIP_PREBUILD_RANGED", 1, 0, 1) != 0;
+    const unsigned parts = (rh::kDecodeParts & ~(fused ? 0u : (1u << rh::KP_FUSED)) & ~(ranged ? 0u : ((1u << rh::KP_SIZE_R) | (1u << rh::KP_EMIT_R)))) |
+                           ((s->cs->encode_unsupported.empty() && !s->cs->wide) ? rh::kEncodeParts : 0u);      // (a wide schema's Arrow -> Avro pair is compiled by its first rh_encode: the encode generator unrolls every column)
     rh::KernelImage im[rh::KP_COUNT];
     const unsigned started = rh::kernel_images(s->images, *s->cs, parts, rh::CP_BLOCKING, im);
     for (int p = 0; p < rh::KP_COUNT; p++) {

@@ -31,6 +31,7 @@ struct rh_decode_call {
   int K = 0, nnodes = 0, nbuf = 0;
   const DeviceProgram* dp = nullptr;
   const SpecKernel* sk = nullptr;
+  hipFunction_t size_r = nullptr, emit_r = nullptr;     // the ranged pair, when this call launches it (tiles past the LDS window)
   uint64_t narrow_rows = 0, tile = 0, bpc64 = 0, payload = 0;
   uint32_t nblocks = 0;
   uint64_t o_null = 0, o_tot = 48, ctrl_bytes = 0;
@@ -124,9 +125,10 @@ struct rh_decode_call {
         rh_launch_init(P.bufptr, d_sizes, dp->desc, (uint32_t)nbuf, k, P.first_bad, stream)) throw HipError("k_init launch failed");
     if (n > 0) {
       emit_lds = lds_bytes;
-      if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), ev.at(4))
+      if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), P.ranged ? nullptr : ev.at(4))
              : rh_launch_emit(&P, emit_lds, stream, ev.at(3), ev.at(4)))
         throw HipError("k_emit launch failed");
+      if (P.ranged && launch_module(emit_r, P, nblocks, (uint32_t)tile, emit_lds, stream, nullptr, ev.at(4))) throw HipError("k_emit (ranged) launch failed");
     } else {
       ev.rec(3, stream);
       ev.rec(4, stream);
@@ -303,7 +305,26 @@ struct rh_decode_call {
       if (k0.ok) sk = &k0;
       else if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernel unavailable: " + k0.why);
     }
-    tile = sk ? (uint64_t)rh::spec_tile_records() : (uint64_t)rh::kBlock;   // records per workgroup
+    // The ranged pair behind the size / emit kernels (spec_body.h ranged_tile): while the schema's recent calls met tiles past the
+    // LDS window (rh_schema::ranged_calls, fed by rh_k_publish's tile statistics), or when the caller insists on the specialised
+    // kernels.  A call that meets such tiles without it takes the fallback (the careful walk from global memory) and, large enough,
+    // starts the pair's compile in the background.  RUHVRO_HIP_RANGED=0 / 1: never / always (A/B, tests).
+    if (sk) {
+      const long force = env_long("RUHVRO_HIP_RANGED", -1, 0, 1);
+      const bool want = force == 1 || (force != 0 && (s->ranged_calls.load(std::memory_order_relaxed) > 0 || mode == RH_KERNEL_SPECIALIZED));
+      if (want && !sk->ranged_dead) {
+        hipFunction_t er = sk->emit_r_fn.load(std::memory_order_acquire);
+        // (asked for by the schema's history: never wait for the compile -- the generic kernels take the call meanwhile)
+        if (!er) er = spec_kernel(s, device, (force == 1 || mode == RH_KERNEL_SPECIALIZED) ? rh::CP_BLOCKING : rh::CP_BACKGROUND, false, false, true).emit_r_fn.load(std::memory_order_acquire);
+        if (er) { emit_r = er; size_r = sk->size_r_fn.load(std::memory_order_acquire); }
+      }
+      if (want && !emit_r) {
+        if (mode == RH_KERNEL_SPECIALIZED) throw HipError("specialised kernels for tiles past the LDS window unavailable");
+        sk = nullptr;            // tiles past the window are expected and the pair is not there (yet): the generic kernels
+      }
+    }
+    // records per workgroup: a wide schema's tile is one wavefront on both kernel forms (program.h kWideTile)
+    tile = cs.wide ? (uint64_t)rh::kWideTile : sk ? (uint64_t)rh::spec_tile_records() : (uint64_t)rh::kBlock;
     bpc64 = std::max<uint64_t>((r.sz + tile - 1) / tile, 1);
     const uint64_t nblocks64 = n == 0 ? 0 : (uint64_t)(k - 1) * bpc64 + (r.rows_last + tile - 1) / tile;
     if (nblocks64 > 0x7FFFFFFFull / std::max(K, 1)) throw std::invalid_argument("too many records for one call");
@@ -323,7 +344,7 @@ struct rh_decode_call {
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
     const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
     const uint64_t o_lcnt = align_up(o_flag + 4ull * nblocks, kAlign);
-    const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((K + 1) / 2) * nblocks * tile : 0), kAlign);
+    const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((cs.KL + 1) / 2) * nblocks * tile : 0), kAlign);
     hp.mark("setup");
     ws = Lease(dev_pool(), ws_bytes, device);
     hctrl = Lease(pin_pool(), ctrl_bytes, device);
@@ -334,8 +355,9 @@ struct rh_decode_call {
     P.data = d_data; P.offsets = d_offsets; P.data_len = data_len;
     P.n = n; P.sz = r.sz; P.rows_last = r.rows_last; P.k = k; P.bpc = (uint32_t)bpc64; P.nblocks = nblocks;
     P.prog = dp->prog; P.sym_off = dp->sym_off; P.sym_data = dp->sym_data;
-    P.nops = (int)cs.prog.size(); P.K = K; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
+    P.nops = (int)cs.prog.size(); P.K = K; P.KL = cs.KL; P.tile = (uint32_t)tile; P.ndom = cs.ndom; P.nnodes = nnodes; P.list_depth = cs.list_depth;
     P.nbuf = nbuf; P.cnt_databuf = dp->cnt_databuf;
+    P.ranged = (size_r && emit_r) ? 1u : 0u;
     P.first_bad = (unsigned long long*)ctrl->ptr();
     P.nullcount = (uint32_t*)(ctrl->ptr() + o_null);
     P.null_slots = null_slots;
@@ -349,7 +371,7 @@ struct rh_decode_call {
 
     // LDS: fixed part + input window sized from the mean record length (falls back to global reads
     // for workgroups whose 256 records do not fit)
-    const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs), rh::dom0_bitmap_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
+    const uint32_t lds_fixed = (sk ? rh::spec_lds_fixed_words_host(K, nnodes, (int)(tile / 64), rh::child_bitmap_count(cs), rh::dense_list_count(cs), rh::dom0_bitmap_count(cs)) * 4 : rh_lds_fixed_bytes(K, cs.KL, (int)tile, cs.list_depth, nnodes, nbuf)) + 16;   // + window slack
     payload = geo ? geo->payload_bytes : data_len;
     const uint64_t avg = n ? payload / n + 1 : 16;
     // (tuning / test knobs, read per call: RUHVRO_HIP_WIN_PCT, RUHVRO_HIP_WIN_PAD)
@@ -369,6 +391,12 @@ struct rh_decode_call {
         const uint64_t step = (160 * 1024 / nwg) & ~511ull;
         if (lds_fixed + win > step && step > lds_fixed && step - lds_fixed >= min_win) { win = (step - lds_fixed) & ~15ull; break; }
       }
+    }
+    // A wide schema's tile is one wavefront: the window is kept small enough for 8 of them per CU (records of a hundred and more
+    // columns are large: a window for 64 of them would leave a CU one or two wavefronts) -- tiles past it are walked in ranges.
+    if (cs.wide && win_pct == 115 && win_pad == 2048) {
+      const uint64_t per_wave = (160 * 1024 / 8) & ~511ull;
+      if (per_wave > lds_fixed + 4096) win = std::min<uint64_t>(win, (per_wave - lds_fixed) & ~15ull);
     }
     // (RUHVRO_HIP_WIN_BYTES: the window as given -- 0 = none, every tile is walked from global memory; measurement knob)
     {
@@ -414,9 +442,11 @@ struct rh_decode_call {
     if (try_single(two_sync, ratio_hook)) return;
     timed_size = n > 0 && K > 0;
     if (timed_size) {
-      if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), ev.at(1))
+      // (with the ranged pair: the size kernel's start and the ranged size kernel's stop bracket the pass)
+      if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), P.ranged ? nullptr : ev.at(1))
              : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
         throw HipError("k_size launch failed");
+      if (P.ranged && launch_module(size_r, P, nblocks, (uint32_t)tile, lds_bytes, stream, nullptr, ev.at(1))) throw HipError("k_size (ranged) launch failed");
       if (sized) HIPCHK(hipEventRecord(sized, stream));
       // (the single-submission path scans and lays the arena out in ONE launch, below)
       if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");
@@ -503,9 +533,18 @@ struct rh_decode_call {
         count(RH_CTR_TILES, nblocks);
         count(RH_CTR_CAREFUL_TILES, stw[0]); count(RH_CTR_OVER_WINDOW_TILES, stw[1]);
         count(RH_CTR_REWALKED_WAVES, stw[2]); count(RH_CTR_SUBTILED_TILES, stw[3]);
+        // tiles past the window: this schema's next calls launch the ranged pair (and compile it if need be)
+        if (stw[1]) s->ranged_calls.store(kRangedKeep, std::memory_order_relaxed);
+        else { uint32_t v = s->ranged_calls.load(std::memory_order_relaxed); if (v) s->ranged_calls.compare_exchange_weak(v, v - 1, std::memory_order_relaxed); }
       }
       if (K > 0) std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
       const uint32_t lflag = *(const uint32_t*)(hctrl.ptr() + 8);
+      if (lflag & rh::LF_NEED_RANGED) {      // a tile past the LDS window and no ranged pair in this call: nothing was emitted
+        ctrl->b.clean = published;
+        s->ranged_calls.store(kRangedKeep, std::memory_order_relaxed);
+        r.arena.release();
+        throw NeedRanged();
+      }
       if (single) {
         ctrl->b.clean = published;
         if (lflag) {            // a column outgrew its capacity (or the capacity layout was refused): the two-pass path decides
@@ -543,6 +582,11 @@ struct rh_decode_call {
         HIPCHK(hipMemcpyAsync(hctrl.ptr(), ctrl->ptr(), ctrl_bytes, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         check_bad(hctrl.ptr());
+        if (*(const uint32_t*)(hctrl.ptr() + 8) & rh::LF_NEED_RANGED) {
+          ctrl->b.clean = false;
+          s->ranged_calls.store(kRangedKeep, std::memory_order_relaxed);
+          throw NeedRanged();
+        }
         std::memcpy(totals.data(), hctrl.ptr() + o_tot, 8ull * K * k);
       }
       exact_tail();
@@ -795,7 +839,6 @@ void settle(rh_device_result* r) {
   // generic kernels (a child row domain beyond 32-bit indexing -- which the two-pass repeat may itself run into)
   auto rerun = [&](int add_flags, bool generic) {
     call->drain();
-    if (generic) count(RH_CTR_WIDE_FALLBACKS);
     rh_opts o = call->opts;
     o.flags = generic ? ((o.flags & ~(3 | RH_ASYNC)) | RH_KERNEL_GENERIC) : ((o.flags & ~RH_ASYNC) | add_flags);
     rh_stats st2;
@@ -828,6 +871,10 @@ void settle(rh_device_result* r) {
     } catch (const NeedTwoPass&) {
       rerun(RH_INTERNAL_TWO_PASS, false);
     } catch (const NeedWideIndex&) {
+      count(RH_CTR_WIDE_FALLBACKS);
+      rerun(0, true);
+    } catch (const NeedRanged&) {
+      count(RH_CTR_RANGED_RETRIES);
       rerun(0, true);
     }
   } catch (...) {
@@ -883,6 +930,12 @@ rh_device_result* decode_device_impl(rh_schema* s, const uint8_t* d_data, const 
     rh_opts o = default_opts();
     if (opts) o = *opts;
     o.flags = RH_KERNEL_GENERIC;
+    return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats, geo);
+  } catch (const NeedRanged&) {      // tiles past the LDS window, no ranged pair yet: this call on the generic kernels (the pair compiles in the background)
+    count(RH_CTR_RANGED_RETRIES);
+    rh_opts o = default_opts();
+    if (opts) o = *opts;
+    o.flags = (o.flags & ~(3 | RH_ASYNC)) | RH_KERNEL_GENERIC;
     return decode_device_impl1(s, d_data, d_offsets, data_len, n, num_chunks, &o, stats, geo);
   }
 }

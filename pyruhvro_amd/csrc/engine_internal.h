@@ -55,7 +55,7 @@ int rh_launch_publish(void* ctrl, void* host, uint32_t head_words, uint32_t null
                       const uint32_t* tileflag, uint32_t nflags, uint32_t stat_word, void* stream);
 int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop);
 int rh_set_max_lds(uint32_t bytes);
-uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf);
+uint32_t rh_lds_fixed_bytes(int K, int KL, int tile, int list_depth, int nnodes, int nbuf);
 // Arrow -> Avro kernels (encode.hip)
 int rh_launch_esize(const rh::EParams* P, uint32_t lds_bytes, void* stream);
 int rh_launch_eemit(const rh::EParams* P, uint32_t lds_bytes, void* stream);
@@ -77,9 +77,11 @@ struct ValueClassError : std::runtime_error {   // data-dependent failures of ot
   using std::runtime_error::runtime_error;
 };
 struct NeedWideIndex {};   // a chunk buffer reaches 4 GiB: only the generic kernels index that far
+struct NeedRanged {};      // a tile past the LDS window met specialised kernels without their ranged pair (LF_NEED_RANGED): repeat on the generic kernels
 struct NeedTwoPass {};     // the single-pass form outgrew a column capacity (or needs what only the two-pass layout checks): repeat
 
 extern std::atomic<uint64_t> g_counters[RH_CTR_COUNT];     // rh_engine_counters (include/ruhvro_hip.h)
+constexpr uint32_t kRangedKeep = 64;      // calls a schema keeps launching its ranged kernels after the last tile past the LDS window
 inline void count(int which, uint64_t by = 1) { g_counters[which].fetch_add(by, std::memory_order_relaxed); }
 
 #define HIPCHK(expr)                                                                          \
@@ -335,8 +337,12 @@ struct DeviceProgram {
 };
 
 struct SpecKernel {      // schema-specialised kernels loaded on one device (each kernel is its own code object, kernel_jobs.h)
-  hipModule_t mod[3] = {nullptr, nullptr, nullptr};
+  hipModule_t mod[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipFunction_t size_fn = nullptr, emit_fn = nullptr;
+  // the ranged pair (tiles past the LDS window, spec_body.h ranged_tile): compiled and loaded when the schema first meets such
+  // tiles; both or neither (emit_r_fn is stored last)
+  std::atomic<hipFunction_t> size_r_fn{nullptr}, emit_r_fn{nullptr};
+  bool ranged_dead = false;
   // the single-pass form (decode kernels only): compiled and loaded when a call first asks for it, so it is written while
   // other calls of the schema read it
   std::atomic<hipFunction_t> fused_fn{nullptr};
@@ -364,6 +370,9 @@ struct rh_schema {
   // outgrows its capacities is repeated on the two-pass form and the schema sits the next calls out (backing off: data that
   // keeps changing character stays on the two-pass form, one outlier batch costs eight calls).
   std::vector<double> per_row;
+  // Tiles past the LDS window: calls of this schema that still launch the ranged kernels behind the size / emit kernels -- set to
+  // kRangedKeep by every settled call that met such tiles (rh_k_publish's tile statistics), counted down by the others.
+  std::atomic<uint32_t> ranged_calls{0};
   uint32_t single_cooldown = 0, single_backoff = 0;      // calls the single pass sits out after a fail-over (8, 16, ... 1024; a success clears it)
 };
 
@@ -372,7 +381,7 @@ namespace rhe {
 const DeviceProgram& device_program(rh_schema* s, int device);
 uint64_t spec_min_records();
 // Specialised kernels of this schema on `device` (engine_kernels.cpp): never blocks on a compile unless the policy says so.
-const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy, bool encode = false, bool want_fused = false);
+const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy, bool encode = false, bool want_fused = false, bool want_ranged = false);
 // What a call of `n` records may spend on kernels this schema does not have yet.
 rh::CompilePolicy compile_policy(int mode, uint64_t n);
 int launch_module(hipFunction_t f, const rh::KParams& P, uint32_t grid, uint32_t block, uint32_t lds, hipStream_t stream,

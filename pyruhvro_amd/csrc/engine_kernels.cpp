@@ -52,7 +52,7 @@ hipFunction_t load_part(SpecKernel& k, int slot, const rh::KernelImage& im, int 
 // one finds the objects ready -- or wait for the jobs (RH_KERNEL_SPECIALIZED, an explicit request).  The schema's mutex is
 // only ever held for table look-ups and hipModuleLoadData, never across a compile.  `want_fused`: also the single-pass
 // kernel (compiled on first request).  A failure is remembered (dead, why).
-const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy, bool encode, bool want_fused) {
+const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy, bool encode, bool want_fused, bool want_ranged) {
   std::map<int, std::unique_ptr<SpecKernel>>& table = encode ? s->espec : s->spec;
   SpecKernel* k = nullptr;
   {
@@ -61,10 +61,12 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy
     if (!slot) slot.reset(new SpecKernel);
     k = slot.get();                                   // (entries are never removed while the schema lives)
     if (k->dead) return *k;
-    if (k->ok && (!want_fused || k->fused_dead || k->fused_fn.load(std::memory_order_acquire))) return *k;
+    if (k->ok && (!want_fused || k->fused_dead || k->fused_fn.load(std::memory_order_acquire)) &&
+        (!want_ranged || k->ranged_dead || k->emit_r_fn.load(std::memory_order_acquire))) return *k;
   }
   const int p_size = encode ? rh::KP_ESIZE : rh::KP_SIZE, p_emit = encode ? rh::KP_EEMIT : rh::KP_EMIT;
-  const unsigned parts = (1u << p_size) | (1u << p_emit) | ((want_fused && !encode) ? (1u << rh::KP_FUSED) : 0u);
+  const unsigned parts = (1u << p_size) | (1u << p_emit) | ((want_fused && !encode) ? (1u << rh::KP_FUSED) : 0u) |
+                         ((want_ranged && !encode) ? ((1u << rh::KP_SIZE_R) | (1u << rh::KP_EMIT_R)) : 0u);
   rh::KernelImage im[rh::KP_COUNT];
   const unsigned started = rh::kernel_images(s->images, *s->cs, parts, policy, im);     // (blocks only under CP_BLOCKING)
   if (started && policy == rh::CP_BACKGROUND) g_counters[RH_CTR_BACKGROUND_COMPILES].fetch_add(started, std::memory_order_relaxed);
@@ -91,6 +93,14 @@ const SpecKernel& spec_kernel(rh_schema* s, int device, rh::CompilePolicy policy
       const rh::KernelImage& f = im[rh::KP_FUSED];
       if (f.state == rh::IMG_FAILED || f.state == rh::IMG_NONE) k->fused_dead = true;
       else if (f.state == rh::IMG_READY) k->fused_fn.store(load_part(*k, 2, f, rh::KP_FUSED), std::memory_order_release);
+    }
+    if (k->ok && want_ranged && !encode && !k->ranged_dead && !k->emit_r_fn.load(std::memory_order_relaxed)) {
+      const rh::KernelImage& a = im[rh::KP_SIZE_R], & b = im[rh::KP_EMIT_R];
+      if (a.state == rh::IMG_FAILED || a.state == rh::IMG_NONE || b.state == rh::IMG_FAILED || b.state == rh::IMG_NONE) k->ranged_dead = true;
+      else if (a.state == rh::IMG_READY && b.state == rh::IMG_READY) {
+        k->size_r_fn.store(load_part(*k, 3, a, rh::KP_SIZE_R), std::memory_order_release);
+        k->emit_r_fn.store(load_part(*k, 4, b, rh::KP_EMIT_R), std::memory_order_release);
+      }
     }
   } catch (const std::exception& e) {
     k->dead = true;

@@ -262,7 +262,7 @@ unsigned kernel_images(const std::shared_ptr<KernelImages>& im, const CompiledSc
     if (s.state == IMG_UNKNOWN || (s.state == IMG_NOT_CACHED && policy != CP_CACHED_ONLY)) {
       const std::string src = generate_part_source(cs, part);
       if (src.empty()) { s.state = IMG_NONE; continue; }
-      const std::string key = kernel_cache_key(src, part >= KP_ESIZE);
+      const std::string key = kernel_cache_key(src, kernel_part_is_encode(part));
       std::vector<char> code;
       if (read_file(kernel_cache_dir() + "/" + key + ".hsaco", code) && code.size() > 64) {
         s.code = std::make_shared<const std::vector<char>>(std::move(code));

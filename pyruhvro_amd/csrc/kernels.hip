@@ -33,32 +33,48 @@ namespace rh {
 // --------------------------------------------------------------------------
 // interpreter context: per-lane counters live in LDS ([id][256], conflict-free)
 // --------------------------------------------------------------------------
+template <int T>
 struct ICtx {
   static constexpr bool kWide = true;   // 64-bit buffer indexing: any chunk size
   static constexpr bool kSkip = false;
   static constexpr bool kEnumImm = false;
+  static constexpr bool kWaveCtr = true;      // (wide schemas, program.h F_WAVE_CTR: tested per op)
   static __device__ __forceinline__ bool enum_sym(int, uint32_t, uint32_t&, uint64_t&) { return false; }
-  uint32_t* cnt;             // LDS [K][256]
-  uint32_t* rem;             // LDS [depth][256]
+  uint32_t* cnt;             // LDS [KL][T]
+  uint32_t* rem;             // LDS [depth][T]
   uint32_t* nullcnt;         // LDS [nnodes]
   const uint64_t* bufs;      // LDS [nbuf]   this chunk's buffer addresses
   const uint32_t* gb;        // LDS [K]      chunk-relative base of this workgroup per counter
+  uint32_t* wv;              // LDS [K]      wide schemas: the wavefront's sum (size walk) / running base (emit walk) of every wave counter
   const uint32_t* sym_off;
   const uint8_t* sym_data;
   uint32_t lrow;             // chunk-local row of this lane (domain 0)
   uint32_t tid, lane;
   bool wave_live;            // the wave owns at least one row (uniform)
 
-  __device__ __forceinline__ uint32_t& counter(int id) const { return cnt[id * kBlock + tid]; }
-  __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d * kBlock + tid]; }
+  __device__ __forceinline__ uint32_t& counter(int id) const { return cnt[id * T + tid]; }
+  __device__ __forceinline__ uint32_t& remaining(int d) const { return rem[d * T + tid]; }
   __device__ __forceinline__ void* buf(int id) const { return reinterpret_cast<void*>(bufs[id]); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return gb[id]; }
+  __device__ __forceinline__ void wave_total(int id, uint32_t len) const {
+    const uint32_t t = wave_sum(len);
+    if (lane == 0) wv[id] = t;
+  }
+  __device__ __forceinline__ uint32_t wave_offset(int id, uint32_t len) const {
+    const uint32_t incl = wave_incl_scan(len, lane);
+    const uint32_t base = wv[id];
+    if (lane == 63) wv[id] = base + incl;     // (DS operations of a wavefront execute in order: every lane has read `base`)
+    return base + incl - len;
+  }
+  template <bool ACC>
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
     if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
   }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
   // domain-0 bitmaps: rows == lanes, one 64-bit store per wavefront
+  template <bool ACC>
   __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
+    static_assert(!ACC, "the interpreter walks a wavefront's records in one piece");
     if (lane == 0 && wave_live) st_global<uint64_t, kWide>(this->buf(buf), lrow >> 6, m);
   }
   // child-domain bitmaps: one fire-and-forget atomic per bit on zeroed words (k_init).  The specialised kernels build
@@ -71,8 +87,8 @@ struct ICtx {
 // --------------------------------------------------------------------------
 // the interpreter: scalar program counter, one handler call per op
 // --------------------------------------------------------------------------
-template <bool EMIT, class Src>
-__device__ __forceinline__ void walk(const KParams& P, const ICtx& c, const Src& src, Lane& L) {
+template <bool EMIT, class Ctx, class Src>
+__device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& src, Lane& L) {
   int pc = 0;
   for (;;) {
     pc = __builtin_amdgcn_readfirstlane(pc);
@@ -107,32 +123,35 @@ __device__ __forceinline__ void walk(const KParams& P, const ICtx& c, const Src&
 // LDS carving shared by k_size / k_emit
 // --------------------------------------------------------------------------
 struct Smem {
-  uint32_t* cnt;      // [K][256]
-  uint32_t* rem;      // [list_depth][256]
-  uint32_t* wtot;     // [K][4]
+  uint32_t* cnt;      // [KL][T]   per-lane counters (all K of them unless the schema is wide)
+  uint32_t* rem;      // [list_depth][T]
+  uint32_t* wtot;     // [K][NW]
   uint32_t* gb;       // [K]   chunk-relative workgroup base
+  uint32_t* wv;       // [K]   wide schemas only (KL < K): ICtx::wv
   uint32_t* nullcnt;  // [nnodes]
   uint32_t* misc;     // [4]: 0 = lowest erroring tid
   uint64_t* bufs;     // [nbuf]
   uint8_t* win;       // input window (16-byte aligned, +16 bytes of slack)
 };
 
-__host__ __device__ inline uint32_t lds_fixed_words(int K, int list_depth, int nnodes, int nbuf) {
-  const uint32_t k1 = (uint32_t)(K > 0 ? K : 1);
+__host__ __device__ inline uint32_t lds_fixed_words(int K, int KL, int T, int list_depth, int nnodes, int nbuf) {
+  const uint32_t k1 = (uint32_t)(K > 0 ? K : 1), kl1 = (uint32_t)(KL > 0 ? KL : 1);
   const uint32_t k4 = (k1 + 3) & ~3u;
-  return k1 * kBlock + (uint32_t)(list_depth > 0 ? list_depth : 1) * kBlock + k1 * 4 + k4 +
+  return kl1 * (uint32_t)T + (uint32_t)(list_depth > 0 ? list_depth : 1) * (uint32_t)T + ((k1 * (uint32_t)(T / 64) + 3) & ~3u) + k4 + (KL < K ? k4 : 0u) +
          (uint32_t)((nnodes + 3) & ~3) + 4 + 2 * (uint32_t)((nbuf + 1) & ~1);
 }
 
+template <int T>
 __device__ __forceinline__ Smem carve(const KParams& P, uint8_t* smem) {
   Smem s;
-  const uint32_t k1 = (uint32_t)(P.K > 0 ? P.K : 1);
+  const uint32_t k1 = (uint32_t)(P.K > 0 ? P.K : 1), kl1 = (uint32_t)(P.KL > 0 ? P.KL : 1);
   const uint32_t k4 = (k1 + 3) & ~3u;
   uint32_t* p = reinterpret_cast<uint32_t*>(smem);
-  s.cnt = p; p += k1 * kBlock;
-  s.rem = p; p += (P.list_depth > 0 ? P.list_depth : 1) * kBlock;
-  s.wtot = p; p += k1 * 4;
+  s.cnt = p; p += kl1 * T;
+  s.rem = p; p += (P.list_depth > 0 ? P.list_depth : 1) * T;
+  s.wtot = p; p += (k1 * (T / 64) + 3) & ~3u;
   s.gb = p; p += k4;
+  s.wv = p; p += P.KL < P.K ? k4 : 0u;
   s.nullcnt = p; p += ((P.nnodes + 3) & ~3);
   s.misc = p; p += 4;
   s.bufs = reinterpret_cast<uint64_t*>(p); p += 2 * ((P.nbuf + 1) & ~1);
@@ -141,12 +160,12 @@ __device__ __forceinline__ Smem carve(const KParams& P, uint8_t* smem) {
 }
 
 // Host mirror of carve(): LDS bytes in front of the window.
-extern "C" uint32_t rh_lds_fixed_bytes(int K, int list_depth, int nnodes, int nbuf) {
-  return lds_fixed_words(K, list_depth, nnodes, nbuf) * 4;
+extern "C" uint32_t rh_lds_fixed_bytes(int K, int KL, int tile, int list_depth, int nnodes, int nbuf) {
+  return lds_fixed_words(K, KL, tile, list_depth, nnodes, nbuf) * 4;
 }
 
-template <bool EMIT>
-__device__ __forceinline__ void run_walk(const KParams& P, const ICtx& c, const Smem& s, Lane& L, bool fits, uint64_t wb16) {
+template <bool EMIT, int T>
+__device__ __forceinline__ void run_walk(const KParams& P, const ICtx<T>& c, const Smem& s, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
     LdsSrc src{s.win};
     walk<EMIT>(P, c, src, L);
@@ -156,46 +175,55 @@ __device__ __forceinline__ void run_walk(const KParams& P, const ICtx& c, const 
   }
 }
 
-__device__ __forceinline__ ICtx make_ctx(const KParams& P, const Smem& s, const Geo& g, uint32_t tid) {
-  ICtx c;
-  c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.bufs = s.bufs; c.gb = s.gb;
+template <int T>
+__device__ __forceinline__ ICtx<T> make_ctx(const KParams& P, const Smem& s, const Geo& g, uint32_t tid) {
+  ICtx<T> c;
+  c.cnt = s.cnt; c.rem = s.rem; c.nullcnt = s.nullcnt; c.bufs = s.bufs; c.gb = s.gb; c.wv = s.wv;
   c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.tid = tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
   return c;
 }
 
 // --------------------------------------------------------------------------
-// k_size
+// k_size.  T = records (= threads) per tile: 256, or 64 for a wide schema (program.h kWideTile: one wavefront per tile, so that
+// the byte counters of domain-0 columns are wave counters with no per-lane storage -- ICtx::wave_total / wave_offset)
 // --------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) {
+template <int T>
+__device__ __forceinline__ void k_size_body(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const Smem s = carve(P, smem);
+  constexpr int NW = T / 64;
+  const Smem s = carve<T>(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Geo g = geometry(P, blockIdx.x);
+  const Geo g = geometry<T>(P, blockIdx.x);
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
-  if (fits) stage_window(P, s.win, wb16, we, tid);
-  for (int k = 0; k < P.K; k++) s.cnt[k * kBlock + tid] = 0;
+  if (fits) stage_window<T>(P, s.win, wb16, we, tid);
+  for (int k = 0; k < P.KL; k++) s.cnt[k * T + tid] = 0;
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
 
   Lane L;
   lane_init(L, P, g, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
-  const ICtx c = make_ctx(P, s, g, tid);
+  const ICtx<T> c = make_ctx<T>(P, s, g, tid);
   run_walk<false>(P, c, s, L, fits, wb16);
 
-  for (int k = 0; k < P.K; k++) {
-    uint32_t v = wave_sum(s.cnt[k * kBlock + tid]);
-    if (lane == 0) s.wtot[k * 4 + wave] = v;
+  for (int k = 0; k < P.KL; k++) {
+    uint32_t v = wave_sum(s.cnt[k * T + tid]);
+    if (lane == 0) s.wtot[k * NW + wave] = v;
   }
-  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot
+  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot (and the wave counters' sums in wv)
   if (tid == 0) P.tileflag[blockIdx.x] = fits ? 0u : (uint32_t)TF_OVER_WINDOW;      // (statistics only: this form always walks carefully)
-  if ((int)tid < P.K)
-    P.blocksum[(size_t)tid * P.nblocks + blockIdx.x] =
-        s.wtot[tid * 4] + s.wtot[tid * 4 + 1] + s.wtot[tid * 4 + 2] + s.wtot[tid * 4 + 3];
+  for (int k = tid; k < P.K; k += T) {
+    uint32_t t = 0;
+    if (k < P.KL) { for (int w = 0; w < NW; w++) t += s.wtot[k * NW + w]; }
+    else t = s.wv[k];                                 // (a wide schema's tile is one wavefront: its sum is the tile's)
+    P.blocksum[(size_t)k * P.nblocks + blockIdx.x] = t;
+  }
 }
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_size(KParams P) { k_size_body<kBlock>(P); }
+extern "C" __global__ void __launch_bounds__(kWideTile) rh_k_size_w(KParams P) { k_size_body<kWideTile>(P); }
 
 // --------------------------------------------------------------------------
 // k_scan: one workgroup per (counter, chunk)
@@ -306,7 +334,7 @@ __device__ __forceinline__ void layout_body(const LParams& L, uint64_t* run_sum,
   if (tid == kBlock - 1) {
     const uint64_t acc = wbase + incl;
     const uint64_t used = acc < kBufAlign ? kBufAlign : acc;
-    uint32_t f = flags;
+    uint32_t f = flags | (reinterpret_cast<uint32_t*>(L.ctrl)[2] & (uint32_t)LF_NEED_RANGED);      // (the size kernel's verdict stays)
     if (used > L.capacity) f |= LF_CAPACITY;
     L.ctrl[2] = used;
     reinterpret_cast<uint32_t*>(L.ctrl)[2] = f;
@@ -432,46 +460,57 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_init(void* const* bufp
 // --------------------------------------------------------------------------
 // k_emit
 // --------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
+template <int T>
+__device__ __forceinline__ void k_emit_body(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NW = T / 64;
   // Uniform for the workgroup: first_bad is only honoured when a size pass ran (K > 0) -- it is final before this kernel
   // starts then; without a size pass this kernel is the one that writes it, and waves of one workgroup reading it at
   // different times could disagree about returning ahead of the barriers below.  The layout flag is always final here.
   if ((P.K > 0 && P.first_bad[0] != 0) || reinterpret_cast<const uint32_t*>(P.first_bad)[2] != 0) return;
-  const Smem s = carve(P, smem);
+  const Smem s = carve<T>(P, smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Geo g = geometry(P, blockIdx.x);
+  const Geo g = geometry<T>(P, blockIdx.x);
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
-  if (fits) stage_window(P, s.win, wb16, we, tid);
-  for (int k = 0; k < P.K; k++) s.cnt[k * kBlock + tid] = 0;
-  for (int i = tid; i < P.nnodes; i += kBlock) s.nullcnt[i] = 0;
-  for (int i = tid; i < P.nbuf; i += kBlock)
+  if (fits) stage_window<T>(P, s.win, wb16, we, tid);
+  for (int k = 0; k < P.KL; k++) s.cnt[k * T + tid] = 0;
+  for (int i = tid; i < P.nnodes; i += T) s.nullcnt[i] = 0;
+  for (int i = tid; i < P.nbuf; i += T)
     s.bufs[i] = reinterpret_cast<uint64_t>(P.bufptr[(size_t)g.chunk * P.nbuf + i]);
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
 
   Lane L;
-  const ICtx c = make_ctx(P, s, g, tid);
+  const ICtx<T> c = make_ctx<T>(P, s, g, tid);
 
   if (P.K > 0) {
-    // walk 1 again (cheaper than 4*K bytes/record of HBM round trip), then the in-workgroup scan
-    lane_init(L, P, g, wb16, tid);
-    run_walk<false>(P, c, s, L, fits, wb16);
-    for (int k = 0; k < P.K; k++) {
-      const uint32_t v = s.cnt[k * kBlock + tid];
-      const uint32_t incl = wave_incl_scan(v, lane);
-      if (lane == 63) s.wtot[k * 4 + wave] = incl;
-      s.cnt[k * kBlock + tid] = incl - v;
+    // walk 1 again (cheaper than 4*K bytes/record of HBM round trip), then the in-workgroup scan of the per-lane counters
+    // (the wave counters of a wide schema need neither: ICtx::wave_offset scans them on the spot in walk 2)
+    if (P.KL > 0) {
+      lane_init(L, P, g, wb16, tid);
+      run_walk<false>(P, c, s, L, fits, wb16);
+      for (int k = 0; k < P.KL; k++) {
+        const uint32_t v = s.cnt[k * T + tid];
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s.wtot[k * NW + wave] = incl;
+        s.cnt[k * T + tid] = incl - v;
+      }
+      __syncthreads();
+      if (NW > 1) {
+        for (int k = 0; k < P.KL; k++) {
+          uint32_t base = 0;
+          for (uint32_t w = 0; w < wave; w++) base += s.wtot[k * NW + w];
+          s.cnt[k * T + tid] += base;             // workgroup-local exclusive prefix
+        }
+      }
     }
-    __syncthreads();
-    for (int k = 0; k < P.K; k++) {
-      uint32_t base = 0;
-      for (uint32_t w = 0; w < wave; w++) base += s.wtot[k * 4 + w];
-      s.cnt[k * kBlock + tid] += base;             // workgroup-local exclusive prefix
+    for (int k = tid; k < P.K; k += T) {
+      const uint32_t b = P.blockbase[(size_t)k * P.nblocks + blockIdx.x];
+      s.gb[k] = b;
+      if (k >= P.KL) s.wv[k] = b;                 // the running base of a wave counter starts at the tile's base
     }
-    if ((int)tid < P.K) s.gb[tid] = P.blockbase[(size_t)tid * P.nblocks + blockIdx.x];
     __syncthreads();
   }
 
@@ -480,11 +519,13 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
   run_walk<true>(P, c, s, L, fits, wb16);
 
   report_errors(P, s.misc, L, g, tid, blockIdx.x);   // barrier inside: nullcnt + staging complete
-  for (int i = tid; i < P.nnodes; i += kBlock) {
+  for (int i = tid; i < P.nnodes; i += T) {
     const uint32_t v = s.nullcnt[i];
     if (v) atomicAdd(&P.nullcount[((size_t)i * P.k + g.chunk) * P.null_slots + (blockIdx.x & (P.null_slots - 1))], v);
   }
 }
+extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) { k_emit_body<kBlock>(P); }
+extern "C" __global__ void __launch_bounds__(kWideTile) rh_k_emit_w(KParams P) { k_emit_body<kWideTile>(P); }
 
 }  // namespace rh
 
@@ -493,6 +534,9 @@ extern "C" __global__ void __launch_bounds__(kBlock) rh_k_emit(KParams P) {
 // --------------------------------------------------------------------------
 extern "C" int rh_launch_size(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
   (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
+  if (P->tile == (uint32_t)rh::kWideTile)
+    hipExtLaunchKernelGGL(rh::rh_k_size_w, dim3(P->nblocks), dim3(rh::kWideTile), lds_bytes, (hipStream_t)stream, (hipEvent_t)start, (hipEvent_t)stop, 0, *P);
+  else
   hipExtLaunchKernelGGL(rh::rh_k_size, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
@@ -531,12 +575,18 @@ extern "C" int rh_launch_layout(const rh::LParams* L, void* stream) {
 }
 extern "C" int rh_launch_emit(const rh::KParams* P, uint32_t lds_bytes, void* stream, void* start, void* stop) {
   (void)hipGetLastError();      // (an earlier, unrelated error -- a hipStreamQuery that said "not ready" -- must not be read as this launch\'s)
+  if (P->tile == (uint32_t)rh::kWideTile)
+    hipExtLaunchKernelGGL(rh::rh_k_emit_w, dim3(P->nblocks), dim3(rh::kWideTile), lds_bytes, (hipStream_t)stream, (hipEvent_t)start, (hipEvent_t)stop, 0, *P);
+  else
   hipExtLaunchKernelGGL(rh::rh_k_emit, dim3(P->nblocks), dim3(rh::kBlock), lds_bytes, (hipStream_t)stream, (hipEvent_t)start,
                         (hipEvent_t)stop, 0, *P);
   return (int)hipGetLastError();
 }
 extern "C" int rh_set_max_lds(uint32_t bytes) {
-  int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(rh::rh_k_size), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e) return e;
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(rh::rh_k_emit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  for (const void* f : {reinterpret_cast<const void*>(rh::rh_k_size), reinterpret_cast<const void*>(rh::rh_k_emit),
+                        reinterpret_cast<const void*>(rh::rh_k_size_w), reinterpret_cast<const void*>(rh::rh_k_emit_w)}) {
+    const int e = (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e) return e;
+  }
+  return 0;
 }

@@ -26,7 +26,8 @@ typedef unsigned long uintptr_t;
 namespace rh {
 
 constexpr int kBlock = 256;          // threads (= records) per workgroup
-constexpr int kMaxCounters = 96;     // scanned per-record counters (row domains + string columns)
+constexpr int kWideCounters = 64;    // schemas with more scanned counters (row domains + byte columns) are compiled WIDE: no limit on their number
+constexpr int kWideTile = 64;        // ... records per tile of a wide schema: one wavefront
 constexpr int kMaxListDepth = 8;     // nested array/map levels
 constexpr int kMaxNest = 30;         // nested nullable-record / union / list levels (bit stacks)
 constexpr int kMaxUnionDepth = 8;    // nested N-variant unions (8-bit selector stack in a u64)
@@ -78,6 +79,7 @@ enum OpFlags : int32_t {
   F_NULL_FIRST = 2,  // union was ["null", T]
   F_CAN_NULL = 4,    // node can receive append_null -> it owns a validity bitmap
   F_IS_MAP = 8,
+  F_WAVE_CTR = 16,   // OP_STRING / OP_ENUM of a wide schema in domain 0: the byte counter is a WAVE counter (scanned on the spot, no per-lane state)
 };
 
 struct Op {
@@ -147,6 +149,7 @@ enum LayoutFlag : uint32_t {
   LF_CAPACITY = 1,     // the arena reserved from the schema's size history is too small: the host re-runs the tail exactly
   LF_OFFSET32 = 2,     // a chunk's column exceeds the 2^31-1 limit of 32-bit Arrow offsets
   LF_NEED_WIDE = 4,    // a child row domain reaches 2^28 rows: only the generic kernels index that far
+  LF_NEED_RANGED = 8,  // (set by rh_spec_size) a tile does not fit the LDS window and the ranged kernels were not launched: the host repeats the call
 };
 
 // Per-tile word the size pass leaves for the emit pass (KParams::tileflag) and for the call's statistics (rh_k_publish)
@@ -194,6 +197,8 @@ struct KParams {
   const uint8_t* sym_data;
   int32_t nops;
   int32_t K;                 // counters
+  int32_t KL;                // ... of which the first KL are per-lane counters; the rest are wave counters (wide schemas: KL < K, tile = kWideTile)
+  uint32_t tile;             // records (= threads) per tile of this launch
   int32_t ndom;              // row domains (>= 1)
   int32_t nnodes;
   int32_t list_depth;        // max list nesting (LDS rem[] rows)
@@ -216,6 +221,7 @@ struct KParams {
   const uint64_t* caps;      // [K][k] capacity of every counter's column per chunk (rows / bytes the arena reserves for it)
   uint32_t* tickets;         // [k] next tile of every chunk (zero at launch): tiles are taken in the order workgroups START
   uint32_t null_slots;       // null_slots_for(k): a power of two <= kNullSlots
+  uint32_t ranged;           // 1: the ranged kernels (rh_spec_size_r / rh_spec_emit_r) follow the size / emit kernel of this call: those leave every tile past the window to them
   uint32_t all_careful;      // 1: no size pass classified the tiles (schemas without variable-length output): the emit kernel walks every tile carefully
 };
 

@@ -706,14 +706,37 @@ std::unique_ptr<CompiledSchema> compile_schema(const char* text, size_t len) {
   b.build(top, false, false, cx);
   cs->prog.push_back(Builder::mk(OP_END));
 
-  // counters: row domains first (domain d -> counter d-1), then the string byte columns
+  // counters: row domains first (domain d -> counter d-1), then the string byte columns.
+  // Round 6 (the reference builds its decoder tree for any width, fast_decode.rs:342-370; K was capped
+  // at 96 by per-lane counter storage).  A byte column of DOMAIN 0 is met exactly once per record, so its counter needs no
+  // per-lane storage at all when the scan unit is one wavefront: the size pass sums the lengths of the wavefront on the spot,
+  // the emit pass scans them on the spot on top of the wavefront's base (walk.h F_WAVE_CTR).  A schema with more than
+  // kWideCounters counters is compiled WIDE: tiles of 64 records (one wavefront), the per-lane counters (KL: row domains and the
+  // byte columns inside arrays / maps) numbered first, the wave counters behind them.
   const int ndomc = cs->ndom - 1;
-  for (int pc : b.str_counter_ops) cs->prog[pc].a += ndomc;
-  for (int id : b.data_bufs) cs->bufs[id].counter += ndomc;
-  for (auto& n : cs->nodes)
-    if (n.counter >= 0) n.counter += ndomc;
   cs->K = ndomc + b.nstr;
-  if (cs->K > kMaxCounters) throw SchemaError("schema has too many variable-length columns for the GPU decoder");
+  cs->wide = cs->K > kWideCounters;
+  std::vector<int> newid((size_t)b.nstr, 0);       // local string index -> counter id
+  {
+    int nl = ndomc, nw = 0, inlist = 0;
+    for (int pc : b.str_counter_ops) inlist += cs->prog[pc].dom != 0 ? 1 : 0;
+    for (size_t i = 0; i < b.str_counter_ops.size(); i++) {
+      const Op& o = cs->prog[b.str_counter_ops[i]];
+      const int sidx = o.a;
+      if (!cs->wide) newid[(size_t)sidx] = ndomc + sidx;
+      else if (o.dom != 0) newid[(size_t)sidx] = nl++;
+      else newid[(size_t)sidx] = ndomc + inlist + nw++;
+    }
+    cs->KL = cs->wide ? ndomc + inlist : cs->K;
+  }
+  for (int pc : b.str_counter_ops) {
+    Op& o = cs->prog[pc];
+    o.a = newid[(size_t)o.a];
+    if (cs->wide && o.dom == 0) o.flags |= F_WAVE_CTR;
+  }
+  for (int id : b.data_bufs) cs->bufs[id].counter = newid[(size_t)cs->bufs[id].counter];
+  for (auto& n : cs->nodes)
+    if (n.counter >= 0) n.counter = newid[(size_t)n.counter];
   if (cs->sym_off.empty()) cs->sym_off.push_back(0);
   if (cs->sym_data.empty()) cs->sym_data.push_back(0);
   cs->min_record_bytes = Builder::min_bytes(top);

@@ -101,6 +101,8 @@ struct CompiledSchema {
   std::vector<uint32_t> sym_off;
   std::vector<uint8_t> sym_data;
   int K = 0;                        // counters: [0, ndom-1) row domains 1.., then string byte columns
+  int KL = 0;                       // ... of which the first KL live per lane (all of them unless `wide`)
+  bool wide = false;                // more than kWideCounters counters: tiles of one wavefront, wave counters (program.h F_WAVE_CTR)
   int ndom = 1;
   int list_depth = 0;
   uint32_t min_record_bytes = 0;

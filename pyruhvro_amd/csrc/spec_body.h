@@ -62,19 +62,38 @@ template <class S>
 struct SCtx {
   static constexpr int K1 = S::K > 0 ? S::K : 1;
   static constexpr int KP = (K1 + 3) & ~3;           // words per wavefront row of wtot
+  // Wide schemas (schema.cpp: more than kWideCounters counters; TILE = 64): only the first KL counters -- row domains and the byte
+  // columns inside arrays / maps -- live per lane; the byte columns of domain 0 behind them are WAVE counters (walk.h F_WAVE_CTR)
+  static constexpr int KL = S::KL;
+  static constexpr int KL1 = KL > 0 ? KL : 1;
+  static constexpr int KLP = (KL1 + 3) & ~3;
+  static constexpr bool kWaveCtr = S::KL < S::K;
+  static_assert(!kWaveCtr || S::TILE == 64, "wave counters need tiles of one wavefront");
+  uint32_t* wv;                                       // LDS [K] (wide): size walk = this walk's wavefront sum per wave counter;
+                                                      //                 emit walk = the wavefront's running chunk-relative base
+  __device__ __forceinline__ void wave_total(int id, uint32_t len) const {
+    const uint32_t t = wave_sum(len);
+    if (lane == 0) wv[id] = t;                        // (every wave counter is met once per walk: a plain store; committed by the caller)
+  }
+  __device__ __forceinline__ uint32_t wave_offset(int id, uint32_t len) const {
+    const uint32_t incl = wave_incl_scan(len, lane);
+    const uint32_t base = wv[id];
+    if (lane == 63) wv[id] = base + incl;             // (DS operations of a wavefront execute in order: every lane has read `base`)
+    return base + incl - len;
+  }
   static constexpr bool kWide = false;   // 32-bit byte offsets into each buffer (host guards: buffers < 4 GiB per chunk)
   static constexpr bool kSkip = false;
   static constexpr bool kDense = S::NDENSE > 0;
   uint32_t* dtab;                                     // LDS [kDenseCap]: this wavefront's item-position table (dense_list)
   const uint32_t* wtot_w;                             // LDS: this wavefront's row of wtot: wtot_w[k] = its total of counter k
-  mutable uint32_t cnt[K1];                           // per-lane counters (registers)
+  mutable uint32_t cnt[KL1];                          // per-lane counters (registers)
   mutable uint32_t rem[S::DEPTH > 0 ? S::DEPTH : 1];  // items left in the current block, per list depth
   // this chunk's row of the buffer-address table.  Read-only for the whole launch, so it is addressed through the
   // constant address space: every use is a scalar load the compiler may re-issue instead of keeping (and spilling)
   // 2 x NBUF SGPRs -- with the addresses held in registers a third of the emit kernel's VALU instructions were
   // v_readlane reloads of spilled SGPRs.
   const __attribute__((address_space(4))) uint64_t* bufp;
-  uint32_t gb[K1];                                    // chunk-relative base of this workgroup per counter
+  uint32_t gb[KL1];                                   // chunk-relative base of this workgroup per (per-lane) counter
   uint32_t* nullcnt;                                  // LDS [NNODES]: null rows of child domains (one atomic per null row)
   uint32_t* nullw_w;                                  // LDS [NNODES][NW] + this wave: null rows of domain-0 fields, per wavefront
   const uint32_t* sym_off;
@@ -93,12 +112,13 @@ struct SCtx {
   // A domain-0 field is visited exactly once per wavefront and tile, so its null count of the wave is a plain store into
   // the wave's own word (summed per tile at the flush), not an atomic add: the compiler expands a wave-uniform LDS atomic
   // into ~19 instructions (its atomic optimiser: mbcnt / bcnt / mul around a single-lane ds_add) per nullable field.
+  // (ACC: a wavefront that walks its records in several ranges -- ranged_tile -- adds to the word, zeroed at the tile's start)
+  template <bool ACC>
   __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const {
-#ifdef RH_V_NONULLW
-    if (lane == 0 && n) atomicAdd(&nullcnt[node], n);
-#else
-    if (lane == 0) nullw_w[node * (S::TILE / 64)] = n;
-#endif
+    if (lane == 0) {
+      if constexpr (ACC) nullw_w[node * (S::TILE / 64)] += n;
+      else nullw_w[node * (S::TILE / 64)] = n;
+    }
   }
   __device__ __forceinline__ void add_nulls_lane(int node) const { atomicAdd(&nullcnt[node], 1u); }
   // Bits of child-domain bitmaps (validity / boolean values of list items, map values ...).  A tile's rows of a child
@@ -109,12 +129,17 @@ struct SCtx {
   // k_emit 0.354 -> 0.113 ms, profiles/r02f_child_bitmap_ab.jsonl).  Rows beyond the LDS words (a tile with > ~2000 child rows) take the global form.
   // domain-0 bitmaps: rows == lanes, one ballot and one 64-bit store per wavefront and field.  (Collecting the ~15 words
   // of a wave in one VGPR with v_writelane and storing them once was measured: no gain, profiles/r02g_variants_ab.txt.)
+  template <bool ACC>
   __device__ __forceinline__ void put_word0(int buf, uint64_t m) const {
     // the tile's domain-0 bitmap words are collected in LDS and stored by ONE instruction per workgroup (spec_emit tail)
     // instead of one single-lane store per field and wave: a store costs the vector-memory path ~16 cycles even with one
     // active lane (tools/storecost.hip), 11-14 such words per wave on the benchmark schema (k_emit -4.2 %,
     // profiles/r03y_variants_ab.txt; the per-WAVE collection of round 2 -- v_writelane, one store per wave -- had not paid)
-    if (lane == 0) bmw0[S::bm0slot(buf) * (S::TILE / 64) + (lrow & (S::TILE - 1)) / 64] = m;
+    if (lane == 0) {
+      uint64_t& w = bmw0[S::bm0slot(buf) * (S::TILE / 64) + (lrow & (S::TILE - 1)) / 64];
+      if constexpr (ACC) w |= m;      // (ranged_tile: the bits of this range's records onto the zeroed word)
+      else w = m;
+    }
   }
   uint64_t* bmw0;                                     // LDS [NB0][NW]: this tile's domain-0 bitmap words
   uint32_t* bm;                                       // LDS [NBM][kBmWords]
@@ -220,17 +245,28 @@ template <class S, int LID, int D, int DEPTH, class Src, class Body>
 __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lane& L, Body&& body) {
   constexpr int NW = S::TILE / 64;
   uint32_t* const tab = c.dtab;
-  const uint32_t n_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.wtot_w[D]);   // items of this wavefront
-  const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cnt[D]);         // tile-local row of its first item
-  uint32_t carry[SCtx<S>::K1];                               // running tile-local byte offset of the body's string columns
-  static_for<0, S::K>([&](auto ik) {
+  // Over a SlideSrc the wavefront walks only the records of ONE range of its tile (ranged_tile): the items are those of the
+  // lanes that are live here -- rows [first live lane's prefix, ...) -- and their number is only known once phase A has met
+  // them (`top`), so the rounds end when no lane has an item left instead of at the wavefront's total.
+  int first = 0;
+  if constexpr (Src::kSlide) {
+    const uint64_t lv = __ballot(L.live);
+    if (lv == 0) { L.live = false; L.pres = false; return; }
+    first = (int)__builtin_ctzll(lv);
+  }
+  const uint32_t n_w = Src::kSlide ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)c.wtot_w[D]);   // items of this wavefront
+  const uint32_t wbase = (uint32_t)__builtin_amdgcn_readlane((int)c.cnt[D], first);       // tile-local row of its first item
+  uint32_t carry[SCtx<S>::KL1];                              // running tile-local byte offset of the body's string columns
+  static_for<0, S::KL>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
-    if constexpr (S::dense_body(LID, k)) carry[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.cnt[k]);
+    if constexpr (S::dense_body(LID, k)) carry[k] = (uint32_t)__builtin_amdgcn_readlane((int)c.cnt[k], first);
   });
   uint32_t& rm = c.remaining(DEPTH);
   bool inlist = L.live;                                      // h_list_begin: the row carries a list
   for (uint32_t lo = 0;; lo += kDenseCap) {
     const uint32_t limit = lo + kDenseCap;
+    uint32_t top = 0;                                        // (SlideSrc) one past the last item this lane noted in this round
+    if constexpr (Src::kSlide) { L.live = inlist; src.refill(L, c.lane); }      // (the table is empty here: positions may move)
     // phase A, one lane = one record: note where the items [lo, limit) of the wave start
     for (;;) {
       const bool need = inlist && rm == 0;                   // at a block boundary: count, or the 0 terminator
@@ -244,33 +280,40 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
       const uint32_t idx = c.cnt[D] - wbase;                 // row of this lane's next item, relative to the wave's first
       const bool go = inlist && idx < limit;
       if (!__any(go)) break;
-      if (go) tab[idx - lo] = L.cur;
+      if (go) { tab[idx - lo] = L.cur; top = idx + 1; }
       L.live = go; L.pres = go;
       body(IC<0>{}, SkipCtx<SCtx<S>>(c), L);
       if (go) { rm -= 1; c.cnt[D] += 1; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // a wave's DS instructions execute in order: no barrier
     // phase B, one lane = one item
-    const uint32_t nr = n_w > lo ? (n_w - lo < (uint32_t)kDenseCap ? n_w - lo : (uint32_t)kDenseCap) : 0u;
+    uint32_t nr;
+    if constexpr (Src::kSlide) {
+      uint32_t t = top;                                      // the largest `top` of the wavefront: rows are dealt in lane order
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)t, d, 64); t = o > t ? o : t; }
+      nr = t > lo ? t - lo : 0u;
+    } else {
+      nr = n_w > lo ? (n_w - lo < (uint32_t)kDenseCap ? n_w - lo : (uint32_t)kDenseCap) : 0u;
+    }
     for (uint32_t g = 0; g < nr; g += 64) {
       const uint32_t i = g + c.lane;
       const bool act = i < nr;
       Lane Li;
       Li.live = act; Li.pres = act; Li.err = 0; Li.edetail = 0; Li.redo = false;
       Li.pstk = 0; Li.lstk = 0; Li.sstk = 0; Li.la = 0;
-      Li.cur = act ? tab[i] : 0u;
+      Li.cur = act ? tab[i] : Src::kSlide ? tab[0] : 0u;      // (an idle lane reads somewhere harmless: LDS address 0, or the round's first item)
       Li.end = 0xFFFFFFFFu;
       SCtx<S> ci = c;
       ci.cnt[D] = wbase + lo + i;
       {   // item sizes -> offsets of every item inside the body's string columns
         SCtx<S> cz = c;
-        static_for<0, S::K>([&](auto ik) {
+        static_for<0, S::KL>([&](auto ik) {
           constexpr int k = decltype(ik)::value;
           if constexpr (S::dense_body(LID, k)) cz.cnt[k] = 0;
         });
         Lane Lz = Li;
         body(IC<0>{}, SkipCtx<SCtx<S>>(cz), Lz);
-        static_for<0, S::K>([&](auto ik) {
+        static_for<0, S::KL>([&](auto ik) {
           constexpr int k = decltype(ik)::value;
           if constexpr (S::dense_body(LID, k)) {
             const uint32_t d = cz.cnt[k];
@@ -282,18 +325,21 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
       }
       body(IC<1>{}, ci, Li);
     }
-    if (limit >= n_w) break;
+    if constexpr (Src::kSlide) { if (!__any(inlist)) break; }
+    else if (limit >= n_w) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   L.live = false; L.pres = false;                            // (h_list_end restores both from the stacks)
 }
 
-// CAREFUL = false: the branch-free fast walk out of the LDS window (walk.h `reject`); tiles whose window does not
-// fit LDS are always walked carefully, straight from global memory.
+// The walk of a tile whose bytes are staged in the LDS window in one piece (`fits`): cursors become LDS byte addresses (walk.h
+// LdsAbsSrc: k_emit -3 %, profiles/r03ap_abs_window_ab.txt).  !fits: the careful walk straight from global memory, one dependent
+// HBM round trip per head (rounds 1-5's only answer to a tile past the window; profiles/r06_a_*: 6.3 ms where the staged walk
+// takes 1) -- left to the single-pass form; the two-pass kernels give such tiles to the RANGED pair (rh_spec_size_r /
+// rh_spec_emit_r below) and never instantiate it.
 template <class S, bool EMIT, bool CAREFUL>
 __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c, uint8_t* win, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
-    // cursors become LDS byte addresses (walk.h LdsAbsSrc: k_emit -3 %, profiles/r03ap_abs_window_ab.txt)
     const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)win;
     L.cur += wa; L.end += wa;
     LdsAbsSrc src;
@@ -304,9 +350,74 @@ __device__ __forceinline__ void spec_run_walk(const KParams& P, const SCtx<S>& c
   }
 }
 
+// --------------------------------------------------------------------------
+// Tiles past the LDS window (round 6; VERDICT round 5, item 3: they were walked from global memory by the careful form, one
+// dependent HBM round trip per head -- 38 % of the tiles of a skewed workload, 20 ms where the uniform one takes 1).
+//
+// Such a tile is processed in RANGES of consecutive records, split by offsets[]: range [a, b) = the longest run of records
+// from `a` whose bytes fit the window.  It is staged by the whole workgroup like a tile's window and walked -- fast forms,
+// trust, item-dense lists and all -- by the lanes that own its records; the other lanes stand by, and a wavefront without a
+// record of the range skips the walk altogether, so every wavefront walks about once whatever the number of ranges.  A SINGLE
+// record larger than the window is a range of its own, `sliding` (walk.h SlideSrc): its first bytes are staged by its own
+// wavefront and the window follows its cursor from list iteration to list iteration, the items of its top-level lists still
+// emitted one lane per item (dense_list) -- what a record with an array of millions of items needs.
+// `f(src, inr, rb16)` is called once per range by every wavefront that owns a record of it (all 64 lanes; inr = this lane's
+// record is in the range; rb16 = payload offset of window byte 0).  Contains workgroup barriers: uniform control flow.
+// --------------------------------------------------------------------------
+template <class S, class F>
+__device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>& s, const Geo& g, uint64_t o1, uint32_t tid, F&& f) {
+  constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
+  const uint32_t wcap = P.win_bytes & ~15u;
+  uint32_t* const rng = s.gbx + SCtx<S>::KP;           // [NW] records of the range per wavefront (the single-pass form's exchange area: unused here)
+  uint32_t a = 0;
+  while (a < g.nrec) {                                 // (workgroup-uniform)
+    const uint64_t rb16 = P.offsets[g.rec0 + a] & ~15ull;
+    const bool fitme = tid >= a && tid < g.nrec && (o1 - rb16) <= (uint64_t)wcap;      // offsets are monotonic: a prefix of [a, nrec)
+    const uint32_t wc = (uint32_t)__popcll(__ballot(fitme));
+    if (lane == 0) rng[wave] = wc;
+    __syncthreads();
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) cnt += rng[w];
+    const bool single = cnt == 0;                      // record `a` alone is larger than the window
+    const uint32_t b = single ? a + 1u : a + cnt;
+    uint32_t staged;
+    if (!single) {
+      const uint64_t re = P.offsets[g.rec0 + b];
+      stage_window<T>(P, s.win, rb16, re, tid);
+      staged = (uint32_t)((re - rb16 + 15) & ~15ull);
+    } else {
+      const uint64_t left = P.data_len - rb16 + 15ull;
+      staged = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
+      if (wave == a / 64u) stage_wave(P.data + rb16, P.data_len - rb16, wa, staged, lane);
+    }
+    __syncthreads();
+    const bool inr = tid >= a && tid < b;
+    if (__any(inr)) {
+      const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, single};
+      f(src, inr, rb16);
+    }
+    __syncthreads();                                   // the window is free for the next range
+    a = b;
+  }
+}
+
+// lane set-up for one range: only the lanes whose record is in it are live; cursors are LDS addresses (window byte 0 = wa)
+__device__ __forceinline__ void lane_init_range(Lane& L, bool inr, uint64_t o0, uint64_t o1, uint64_t rb16, uint32_t wa) {
+  L.live = inr; L.pres = inr;
+  L.err = 0; L.edetail = 0; L.redo = false;
+  L.pstk = 0; L.lstk = 0; L.sstk = 0; L.la = 0;
+  L.cur = wa + (inr ? (uint32_t)(o0 - rb16) : 0u);
+  L.end = wa + (inr ? (uint32_t)(o1 - rb16) : 0u);
+  if (inr && (o1 - rb16) > 0xFFFFFFF0ull - 0x40000ull) L.err = E_EOB;      // a record beyond 32-bit cursors
+}
+
 template <class S>
 __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, const SpecSmem<S>& s, const Geo& g, uint32_t tid) {
-  static_for<0, SCtx<S>::K1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
+  static_for<0, SCtx<S>::KL1>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = 0; c.gb[k] = 0; });
+  c.wv = s.gbx;
   static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
   c.nullcnt = s.nullcnt; c.nullw_w = s.nullw + (tid >> 6); c.bm = s.bm; c.sym_off = P.sym_off; c.sym_data = P.sym_data;
   c.lrow = g.lrow0 + tid; c.lane = tid & 63; c.wave_live = ((tid >> 6) * 64) < g.nrec;
@@ -317,7 +428,11 @@ __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, cons
 // --------------------------------------------------------------------------
 // size pass: per-workgroup counter sums (+ first malformed record)
 // --------------------------------------------------------------------------
-template <class S>
+// RANGED = false: rh_spec_size, the kernel of every tile that fits the window (a tile past it is left to rh_spec_size_r when
+// P.ranged says that kernel follows, else walked by the fallback above).  RANGED = true: rh_spec_size_r, which only works on the
+// tiles past the window (ranged_tile) -- a code object of its own, compiled when a schema first meets such tiles, so that the
+// hot kernel's registers, code size and compile time are those of the tiles that fit.
+template <class S, bool RANGED = false>
 __device__ __forceinline__ void spec_size(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SpecSmem<S> s(P, smem);
@@ -331,40 +446,83 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
+  if (RANGED ? fits : !fits) {      // (workgroup-uniform, ahead of every barrier) the other kernel's tile ...
+    // ... or nobody's: the ranged pair is not part of this call.  The call is refused (LF_NEED_RANGED: k_init / k_emit return at
+    // once) and the host repeats it -- on the generic kernels, while the pair compiles; with the pair from then on.
+    if (!RANGED && P.ranged == 0 && tid == 0) atomicOr(reinterpret_cast<uint32_t*>(P.first_bad) + 2, (uint32_t)LF_NEED_RANGED);
+    return;
+  }
   if (fits) stage_window<T>(P, s.win, wb16, we, tid);
   if (tid == 0) { s.misc[0] = 0xFFFFFFFFu; s.misc[2] = 0; }
+  if constexpr (SCtx<S>::kWaveCtr) for (int k = S::KL + (int)tid; k < S::K; k += T) s.wtot[k] = 0;      // (one wavefront per tile: its row of wtot)
   __syncthreads();
   RH_MARK(16);
+  // wide schemas: a walk leaves the wavefront's sum of every wave counter in c.wv (SCtx::wave_total); the walk that counts -- the
+  // fast one, or the careful one behind it -- is added to the tile's totals
+  auto commit_wave_counters = [&]() {
+    if constexpr (SCtx<S>::kWaveCtr) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int k = S::KL + (int)lane; k < S::K; k += 64) s.wtot[k] += s.gbx[k];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  };
 
   Lane L;
-  lane_init_from(L, g, o0, o1, wb16, tid);
-  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
   RH_MARK(17);
-  spec_run_walk<S, false, false>(P, c, s.win, L, fits, wb16);
-  bool careful = !fits;
-  uint32_t tflag = fits ? 0u : (uint32_t)TF_OVER_WINDOW;
-  L.redo = L.redo || L.cur > L.end;      // the one bounds check of the fast walk (walk.h read_head): a cursor past its record's end
-  if (__any(L.redo)) {   // some record of this wave left the fast wire forms (or is malformed): walk the wave again, carefully
-    careful = true;
-    tflag |= (uint32_t)TF_REWALK_ONE;
-    spec_ctx_init(c, P, s, g, tid);
-    lane_init_from(L, g, o0, o1, wb16, tid);
-    if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-    spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
+  bool careful = false;
+  uint32_t tflag = 0;
+  if constexpr (!RANGED) {
+    {
+      lane_init_from(L, g, o0, o1, wb16, tid);
+      spec_run_walk<S, false, false>(P, c, s.win, L, true, wb16);
+      L.redo = L.redo || L.cur > L.end;      // the one bounds check of the fast walk (walk.h read_head): a cursor past its record's end
+      if (__any(L.redo)) {   // some record of this wave left the fast wire forms (or is malformed): walk the wave again, carefully
+        careful = true;
+        tflag |= (uint32_t)TF_REWALK_ONE;
+        spec_ctx_init(c, P, s, g, tid);
+        lane_init_from(L, g, o0, o1, wb16, tid);
+        spec_run_walk<S, false, true>(P, c, s.win, L, true, wb16);
+      }
+    }
+    commit_wave_counters();
+  } else {
+    // the tile does not fit the window: its records in ranges (ranged_tile), each walked like a tile of its own
+    tflag = (uint32_t)(TF_OVER_WINDOW | TF_SUBTILED);
+    lane_init_range(L, false, 0, 0, 0, 0);
+    const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
+    ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src0, bool inr, uint64_t rb16) {
+      Lane Lr;
+      lane_init_range(Lr, inr, o0, o1, rb16, wa);
+      const SlideSrc src = src0;           // (a sliding range moves ITS copy of the window along: refill)
+      S::template walk<false, false>(c, src, Lr);
+      Lr.redo = Lr.redo || Lr.cur > Lr.end;
+      if (__any(Lr.redo)) {
+        careful = true;
+        if (!(tflag & (uint32_t)TF_REWALK_ONE)) tflag |= (uint32_t)TF_REWALK_ONE;      // (counted once per wavefront)
+        static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; if (inr) c.cnt[k] = 0; });
+        static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
+        lane_init_range(Lr, inr, o0, o1, rb16, wa);
+        const SlideSrc src2 = src0;        // the record again from its first byte: a window that has moved is staged anew
+        if (src0.sliding && src.g != src0.g) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
+        S::template walk<false, true>(c, src2, Lr);
+      }
+      commit_wave_counters();
+      if (inr) L = Lr;
+    });
   }
   RH_MARK(18);
 
   // per-record counters -> HBM (16 bits each, record-major: lanecnt_store) so that k_emit can skip its size walk
   bool sat = false;
-  constexpr int NDW = (S::K + 1) / 2;
+  constexpr int NDW = (S::KL + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};
   // No per-counter clamp (a counter beyond 16 bits flags the tile and k_emit sizes it again: the packed
   // values of a flagged tile are never read), and when every counter of the wave is below 1024 the wave totals are
   // reduced two counters per dword (64 x 1023 < 2^16: no carry between the halves) -- half the DPP reductions (k_size -2.6 %, profiles/r03ad_variants_ab.txt)
   uint32_t allor = 0;
-  static_for<0, S::K>([&](auto ik) {
+  static_for<0, S::KL>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
     const uint32_t cv = c.cnt[k];
     allor |= cv;
@@ -377,21 +535,21 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
       const uint32_t v = wave_sum(packed[d]);
       if (lane == 0) {
         s.wtot[wave * KP + 2 * d] = v & 0xFFFFu;
-        if constexpr (2 * d + 1 < S::K) s.wtot[wave * KP + 2 * d + 1] = v >> 16;
+        if constexpr (2 * d + 1 < S::KL) s.wtot[wave * KP + 2 * d + 1] = v >> 16;
       }
     });
   } else {
-    static_for<0, S::K>([&](auto ik) {
+    static_for<0, S::KL>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
       const uint32_t v = wave_sum(c.cnt[k]);
       if (lane == 0) s.wtot[wave * KP + k] = v;
     });
   }
-  if constexpr (S::K > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
+  if constexpr (S::KL > 0) lanecnt_store<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const bool anysat = __any(sat);
   // (TileFlag: the re-walk count is ADDED, one per wavefront; the other bits are the same for every wavefront that sets them)
-  if (lane == 0 && (anysat || careful)) {
-    atomicOr(&s.misc[2], (anysat ? (uint32_t)TF_SATURATED : 0u) | (careful ? (uint32_t)TF_CAREFUL : 0u) | (tflag & (uint32_t)TF_OVER_WINDOW));
+  if (lane == 0 && (anysat || careful || tflag)) {
+    atomicOr(&s.misc[2], (anysat ? (uint32_t)TF_SATURATED : 0u) | (careful ? (uint32_t)TF_CAREFUL : 0u) | (tflag & (uint32_t)(TF_OVER_WINDOW | TF_SUBTILED)));
     if (tflag & (uint32_t)TF_REWALK_ONE) atomicAdd(&s.misc[2], (uint32_t)TF_REWALK_ONE);
   }
   report_errors(P, s.misc, L, g, tid, tile);   // contains the barrier that publishes wtot and misc[2]
@@ -408,7 +566,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
 // --------------------------------------------------------------------------
 // emit pass: re-size, scan inside the workgroup, materialise
 // --------------------------------------------------------------------------
-template <class S>
+template <class S, bool RANGED = false>      // (RANGED: rh_spec_emit_r, the tiles past the window -- see spec_size)
 __device__ __forceinline__ void spec_emit(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // the size pass found a malformed record, or the layout kernel refused (program.h LayoutFlag): nothing to emit.
@@ -424,24 +582,26 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
   const uint64_t wb = P.offsets[g.rec0], we = P.offsets[g.rec0 + g.nrec];
+  if (RANGED == ((we - (wb & ~15ull)) <= (uint64_t)P.win_bytes)) return;      // the other kernel's tile (without that kernel the call was refused: LF_NEED_RANGED)
   Lane L;
   SCtx<S> c;
   spec_ctx_init(c, P, s, g, tid);
   // uniform per-workgroup inputs, requested before the window so their latency hides behind it
   c.bufp = (const __attribute__((address_space(4))) uint64_t*)(reinterpret_cast<uintptr_t>(P.bufptr) + (size_t)g.chunk * S::NBUF * 8);
-  static_for<0, S::K>([&](auto ik) {
+  static_for<0, S::KL>([&](auto ik) {
     constexpr int k = decltype(ik)::value;
     c.gb[k] = P.blockbase[(size_t)k * P.nblocks + tile];
   });
+
   // this record's counters as k_size left them (requested with the window, so no extra round trip)
   // (all_careful: no size pass classified the tiles -- K == 0, tileflag is not even written -- or RUHVRO_HIP_NO_TRUST;
   //  a saturated counter, bit 0, still sends the tile through the re-size walk)
   const uint32_t tflag = (S::K > 0 ? P.tileflag[tile] : 0u) | (P.all_careful ? 2u : 0u);
   const uint32_t rewalk = tflag & 1u;
   const bool careful = (tflag & 2u) != 0;
-  constexpr int NDW = (S::K + 1) / 2;
+  constexpr int NDW = (S::KL + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};      // two 16-bit counters per dword, as k_size left them (unpacked after the scan)
-  if constexpr (S::K > 0) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
+  if constexpr (S::KL > 0) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);
@@ -449,30 +609,40 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   for (int i = tid; i < S::NNODES; i += T) s.nullcnt[i] = 0;
   for (int i = tid; i < S::NNODES * NW; i += T) s.nullw[i] = 0;
   for (int i = tid; i < S::NBM * kBmWords; i += T) s.bm[i] = 0;
+  if constexpr (RANGED) for (int i = tid; i < S::NB0 * NW; i += T) s.bmw0[i] = 0;      // (ranged_tile ORs a wavefront's bitmap words together)
   if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
   __syncthreads();
   RH_MARK(1);
+  const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
 
-  if (S::K > 0) {
+  if (S::KL > 0) {
     bool narrow = !rewalk;
     if (rewalk) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
-      static_for<0, S::K>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
-      lane_init_from(L, g, o0, o1, wb16, tid);
-      spec_run_walk<S, false, true>(P, c, s.win, L, fits, wb16);
+      static_for<0, S::KL>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
+      if constexpr (!RANGED) {
+        lane_init_from(L, g, o0, o1, wb16, tid);
+        spec_run_walk<S, false, true>(P, c, s.win, L, true, wb16);
+      } else {
+        ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src, bool inr, uint64_t rb16) {
+          Lane Lr;
+          lane_init_range(Lr, inr, o0, o1, rb16, wa);
+          S::template walk<false, true>(c, src, Lr);
+        });
+      }
     } else {
       // every counter of the wave below 1024: the inclusive scan of a PACKED dword cannot carry from its low half into
       // its high half (64 x 1023 < 2^16), so the wave scans two counters per dword -- half the DPP adds
       uint32_t allor = 0;
       static_for<0, NDW>([&](auto id) { allor |= packed[decltype(id)::value]; });
       narrow = !__any((allor & 0xFC00FC00u) != 0);
-      if (!narrow) static_for<0, S::K>([&](auto ik) {
+      if (!narrow) static_for<0, S::KL>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
         c.cnt[k] = (k & 1) ? packed[k / 2] >> 16 : packed[k / 2] & 0xFFFFu;
       });
     }
     RH_MARK(3);
     if (narrow) {
-      uint32_t tot[SCtx<S>::KP] = {};
+      uint32_t tot[SCtx<S>::KLP] = {};
       static_for<0, NDW>([&](auto id) {
         constexpr int d = decltype(id)::value;
         const uint32_t v = packed[d];
@@ -480,17 +650,17 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
         const uint32_t ex = incl - v;
         c.cnt[2 * d] = ex & 0xFFFFu;
         tot[2 * d] = incl & 0xFFFFu;
-        if constexpr (2 * d + 1 < S::K) { c.cnt[2 * d + 1] = ex >> 16; tot[2 * d + 1] = incl >> 16; }
+        if constexpr (2 * d + 1 < S::KL) { c.cnt[2 * d + 1] = ex >> 16; tot[2 * d + 1] = incl >> 16; }
       });
       if (lane == 63) {      // this wavefront's totals: one contiguous row (16-byte stores)
-        static_for<0, SCtx<S>::KP / 4>([&](auto iq) {
+        static_for<0, SCtx<S>::KLP / 4>([&](auto iq) {
           constexpr int q = decltype(iq)::value;
           v4w x; x.x = tot[4 * q]; x.y = tot[4 * q + 1]; x.z = tot[4 * q + 2]; x.w = tot[4 * q + 3];
           *reinterpret_cast<v4w*>(s.wtot + wave * KP + 4 * q) = x;
         });
       }
     } else {
-      static_for<0, S::K>([&](auto ik) {
+      static_for<0, S::KL>([&](auto ik) {
         constexpr int k = decltype(ik)::value;
         const uint32_t v = c.cnt[k];
         const uint32_t incl = wave_incl_scan(v, lane);
@@ -506,9 +676,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
       // LDS reads at most); every lane then takes counter k's sum from lane k with v_readlane: 2 VALU per counter, not
       // the 5-6 of selecting and adding NW - 1 broadcast totals per counter in every lane
       // (v_readlane selects among 64 lanes: schemas with more counters -- up to kMaxCounters = 96 -- take them 64 at a time)
-      static_for<0, (S::K + 63) / 64>([&](auto ig) {
+      static_for<0, (S::KL + 63) / 64>([&](auto ig) {
         constexpr int k0 = decltype(ig)::value * 64;
-        constexpr int kn = S::K - k0 < 64 ? S::K - k0 : 64;
+        constexpr int kn = S::KL - k0 < 64 ? S::KL - k0 : 64;
         uint32_t prev = 0;
         if (lane < (uint32_t)kn) {
           for (int w = 0; w < NW - 1; w++) prev += (int)wave > w ? s.wtot[w * KP + k0 + lane] : 0u;
@@ -522,13 +692,34 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   }
 
   RH_MARK(6);
-  lane_init_from(L, g, o0, o1, wb16, tid);
-  if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-  if (careful) {
-    spec_run_walk<S, true, true>(P, c, s.win, L, fits, wb16);
+  // wide schemas: the tile's chunk-relative base of every wave counter -> LDS, where SCtx::wave_offset keeps it running
+  // (behind the re-size walk of a saturated tile, whose wave_total calls use the same words)
+  if constexpr (SCtx<S>::kWaveCtr) {
+    for (int k = S::KL + (int)tid; k < S::K; k += T) s.gbx[k] = P.blockbase[(size_t)k * P.nblocks + tile];
+    __syncthreads();
+  }
+  if constexpr (!RANGED) {
+    lane_init_from(L, g, o0, o1, wb16, tid);
+    if (careful) {
+      spec_run_walk<S, true, true>(P, c, s.win, L, true, wb16);
+    } else {
+      spec_run_walk<S, true, false>(P, c, s.win, L, true, wb16);
+      if (L.redo) L.err = E_INTERNAL;   // k_size walks the same bytes and would have flagged the tile
+    }
   } else {
-    spec_run_walk<S, true, false>(P, c, s.win, L, fits, wb16);
-    if (L.redo) L.err = E_INTERNAL;   // k_size walks the same bytes and would have flagged the tile
+    // the tile in ranges, as the size pass walked it (ranged_tile: same offsets, same window, same ranges)
+    lane_init_range(L, false, 0, 0, 0, 0);
+    ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src, bool inr, uint64_t rb16) {
+      Lane Lr;
+      lane_init_range(Lr, inr, o0, o1, rb16, wa);
+      if (careful) {
+        S::template walk<true, true>(c, src, Lr);
+      } else {
+        S::template walk<true, false>(c, src, Lr);
+        if (Lr.redo) Lr.err = E_INTERNAL;
+      }
+      if (inr) L = Lr;
+    });
   }
   RH_MARK(7);
   report_errors(P, s.misc, L, g, tid, tile);   // barrier inside: nullcnt + staging complete

@@ -9,12 +9,17 @@ namespace rh {
 
 // Records (= threads) per workgroup of the specialised kernels: 256 unless RUHVRO_HIP_TILE says 64, 128, 512 or 1024.
 int spec_tile_records();
+// ... of THIS schema: one wavefront (program.h kWideTile) when it is wide, else the above
+int spec_tile_records(const CompiledSchema& cs);
 // The specialised kernels of a schema.  Each is its own hiprtc program (its own code object in the kernel cache), so that a
 // cache miss compiles them side by side (kernel_jobs.cpp) and the opt-in single-pass kernel is only built when asked for.
-enum KernelPart { KP_SIZE = 0, KP_EMIT = 1, KP_FUSED = 2, KP_ESIZE = 3, KP_EEMIT = 4, KP_COUNT = 5 };
-constexpr unsigned kDecodeParts = 7u, kEncodeParts = 24u;
+// (KP_SIZE_R / KP_EMIT_R, round 6: the RANGED pair -- the same passes for the tiles that do not fit the LDS window, spec_body.h
+//  ranged_tile; compiled when a schema first meets such tiles, launched behind the pair above from then on)
+enum KernelPart { KP_SIZE = 0, KP_EMIT = 1, KP_FUSED = 2, KP_ESIZE = 3, KP_EEMIT = 4, KP_SIZE_R = 5, KP_EMIT_R = 6, KP_COUNT = 7 };
+constexpr unsigned kDecodeParts = 7u | 96u, kEncodeParts = 24u;
+inline bool kernel_part_is_encode(int part) { return part == KP_ESIZE || part == KP_EEMIT; }
 inline const char* kernel_part_entry(int part) {
-  static const char* const names[KP_COUNT] = {"rh_spec_size", "rh_spec_emit", "rh_spec_fused", "rh_espec_size", "rh_espec_emit"};
+  static const char* const names[KP_COUNT] = {"rh_spec_size", "rh_spec_emit", "rh_spec_fused", "rh_espec_size", "rh_espec_emit", "rh_spec_size_r", "rh_spec_emit_r"};
   return names[part];
 }
 // HIP source of the specialised decode kernels (rh_spec_size / rh_spec_emit / rh_spec_fused) of this schema; `parts` = the

@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // Global memory has no such cliff (tools/gmemalign.hip), so GlobalSrc reads unaligned directly.
 // --------------------------------------------------------------------------
 struct LdsSrc {
+  static constexpr bool kSlide = false;
   const uint8_t* w;   // LDS window, 16-byte aligned; >= 12 readable bytes past the last record
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return w[p]; }
   // 8 bytes at any byte position: three aligned dwords (ds_read2_b32 + ds_read_b32), two v_alignbyte
@@ -122,7 +123,9 @@ struct LdsSrc {
 #ifndef RH_LDS
 #define RH_LDS __attribute__((address_space(3)))
 #endif
+#define RH_GLOBAL __attribute__((address_space(1)))
 struct LdsAbsSrc {
+  static constexpr bool kSlide = false;
   static __device__ __forceinline__ const RH_LDS uint32_t* dw(uint32_t p) { return reinterpret_cast<const RH_LDS uint32_t*>((uintptr_t)(p & ~3u)); }
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return *reinterpret_cast<const RH_LDS uint8_t*>((uintptr_t)p); }
   __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
@@ -171,9 +174,10 @@ struct LdsAbsSrc {
 };
 
 struct GlobalSrc {
+  static constexpr bool kSlide = false;
   const uint8_t* g;   // payload + window base
   uint64_t lim;       // readable bytes from g
-  __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return g[p]; }
+  __device__ __forceinline__ uint32_t ld1(uint32_t p) const { return (uint64_t)p < lim ? g[p] : 0u; }
   __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
     if ((uint64_t)p + 8 <= lim) return *reinterpret_cast<const u64u*>(g + p);
     uint64_t x = 0;
@@ -203,9 +207,105 @@ struct GlobalSrc {
   }
 };
 
+// One WAVEFRONT stages `nbytes` (a multiple of 16) from global `g` (16-byte aligned) to LDS address `wa` by LDS-DMA: 1 KiB per
+// instruction (global_load_lds_dwordx4: M0 = a wave-uniform LDS base, lane x 16 behind it), all rows in flight together, then
+// vmcnt(0).  No workgroup barrier: for a window only this wavefront reads (SlideSrc::refill).  `gvalid` = bytes readable at g:
+// vectors that would cross it are zero-filled / copied by bytes.
+__device__ __forceinline__ void stage_wave(const uint8_t* g, uint64_t gvalid, uint32_t wa, uint32_t nbytes, uint32_t lane) {
+  const uint32_t nfull = (uint64_t)nbytes <= gvalid ? nbytes : (uint32_t)(gvalid & ~15ull);      // bytes in whole vectors inside the payload
+  const RH_GLOBAL uint8_t* const g0 = reinterpret_cast<const RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(g)) + lane * 16u;
+  for (uint32_t off = 0; off < nfull; off += 1024u) {
+    RH_LDS uint8_t* const lw = reinterpret_cast<RH_LDS uint8_t*>((uintptr_t)(wa + off));
+    if (off + lane * 16u < nfull) __builtin_amdgcn_global_load_lds(g0 + off, lw, 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nfull < nbytes) {                      // the ragged end of the payload: bytes, zero behind them
+    for (uint32_t i = nfull + lane; i < nbytes; i += 64u)
+      *reinterpret_cast<RH_LDS uint8_t*>((uintptr_t)(wa + i)) = (uint64_t)i < gvalid ? g[i] : (uint8_t)0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// Round 6: the source of every tile that does not fit the LDS window in one piece.  Positions are LDS byte addresses like
+// LdsAbsSrc's (window byte 0 = `wa`), but only the first `wlen` bytes behind `wa` are staged: a read that is not completely
+// inside them is served from global memory at the same offset from `g` (per lane; positions in front of the window -- a lane
+// that stayed behind a refill -- included).  Such tiles are processed in RANGES of consecutive records (spec_body.h
+// ranged_tile): a range of records that fits is staged whole (no read ever leaves the window); a single record LARGER than
+// the window (`sliding`) starts with its first bytes staged and, at every list iteration, moves the window up to its cursor
+// (refill) -- the lone lane that owns such a record reads LDS at ~64 cycles per dependent head instead of HBM at ~1500, which
+// was the whole cost of a giant record (profiles/r05t_*: ~1400 cycles per item).
+struct SlideSrc {
+  static constexpr bool kSlide = true;
+  uint32_t wa;            // LDS address of window byte 0 (wave-uniform, 16-byte aligned)
+  mutable uint32_t wlen;  // staged bytes behind wa (wave-uniform; zero-filled past the end of the payload)
+  uint32_t wcap;          // bytes the window can hold (a multiple of 16)
+  mutable const uint8_t* g;   // global address of window byte 0 (16-byte aligned)
+  mutable uint64_t glim;  // readable bytes behind g
+  bool sliding;           // a single record larger than the window: refill() moves the window
+  __device__ __forceinline__ bool in(uint32_t p, uint32_t need) const { return p - wa + need <= wlen; }      // (unsigned: false in front of the window)
+  // Move the window up to the cursor of the one live lane once it has used half of it (called at every list iteration, by
+  // all 64 lanes: wave-uniform).  Every lane's cursor and end are rebased by the same distance; positions noted before the
+  // call (dense_list's table) must have been used up.
+  template <class LaneT>
+  __device__ __forceinline__ void refill(LaneT& L, uint32_t lane) const {
+    if (!sliding) return;
+    const uint64_t lv = __ballot(L.live);
+    if (lv == 0 || (lv & (lv - 1)) != 0) return;                      // (one record per sliding range: one live lane)
+    const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)L.cur, (int)__builtin_ctzll(lv));
+    const uint32_t off = cur - wa;
+    if ((int32_t)off < (int32_t)(wcap / 2)) return;
+    const uint32_t delta = off & ~15u;
+    g += delta;
+    glim -= delta;
+    const uint64_t left = glim + 15ull;
+    wlen = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
+    stage_wave(g, glim, wa, wlen, lane);
+    L.cur -= delta;
+    L.end -= delta;
+  }
+  __device__ __forceinline__ GlobalSrc far(uint32_t p, uint32_t& q) const {
+    // the same position as an offset from a global base that is valid for this lane: g moved forward by refills, the lane may not have
+    const int64_t off = (int64_t)(int32_t)(p - wa);
+    q = 0;
+    // (a lane of the fast walk that lost its record may hold a cursor far behind the payload: nothing is readable there)
+    return GlobalSrc{g + off, off < (int64_t)glim ? (uint64_t)((int64_t)glim - off) : 0ull};
+  }
+  __device__ __forceinline__ uint32_t ld1(uint32_t p) const {
+    if (in(p, 1)) return LdsAbsSrc().ld1(p);
+    uint32_t q; const GlobalSrc f = far(p, q); return f.ld1(q);
+  }
+  __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
+    if (in(p, 12)) return LdsAbsSrc().ld8(p);
+    uint32_t q; const GlobalSrc f = far(p, q); return f.ld8(q);
+  }
+  __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
+  __device__ __forceinline__ uint32_t ld4(uint32_t p) const {
+    if (in(p, 8)) return LdsAbsSrc().ld4(p);
+    uint32_t q; const GlobalSrc f = far(p, q); return f.ld4(q);
+  }
+  __device__ __forceinline__ void ld12(uint32_t p, uint64_t& lo, uint32_t& hi) const {
+    if (in(p, 16)) { LdsAbsSrc().ld12(p, lo, hi); return; }
+    uint32_t q; const GlobalSrc f = far(p, q); f.ld12(q, lo, hi);
+  }
+  __device__ __forceinline__ v4w ld16(uint32_t p) const {
+    if (in(p, 20)) return LdsAbsSrc().ld16(p);
+    uint32_t q; const GlobalSrc f = far(p, q); return f.ld16(q);
+  }
+  // (copy_bytes' batched pieces: aligned dwords around p -- the same bytes through whichever side holds all of them)
+  __device__ __forceinline__ uint32_t ld4a(uint32_t p) const {
+    if (in(p & ~3u, 4)) return LdsAbsSrc().ld4a(p);
+    uint32_t q; const GlobalSrc f = far(p & ~3u, q); return (uint32_t)f.ld8(q);
+  }
+  __device__ __forceinline__ void next2(uint32_t p, int j, uint32_t& d1, uint32_t& d2) const {
+    if (in((p & ~3u) + (uint32_t)j + 4u, 8)) { LdsAbsSrc().next2(p, j, d1, d2); return; }
+    uint32_t q; const GlobalSrc f = far((p & ~3u) + (uint32_t)j + 4u, q);
+    const uint64_t x = f.ld8(q);
+    d1 = (uint32_t)x; d2 = (uint32_t)(x >> 32);
+  }
+};
+
 // Arrow buffers live in HBM: typed global-address-space accessors keep the compiler from emitting
 // flat_* instructions (which tie up both the vector-memory and the LDS counters).
-#define RH_GLOBAL __attribute__((address_space(1)))
 // WIDE = false: the byte offset idx * sizeof(T) is formed in 32 bits, so the store takes the
 // uniform-base + 32-bit-lane-offset addressing form (no 64-bit address arithmetic per lane).  The host
 // only launches kernels built that way when every buffer of a chunk is smaller than 4 GiB.
@@ -250,8 +350,21 @@ __device__ __forceinline__ void st_at_imm(void* base, uint64_t off, T v) {
 template <bool WIDE> struct BufOff { typedef uint64_t type; };
 template <> struct BufOff<false> { typedef uint32_t type; };
 
+__device__ __forceinline__ uint64_t pick_long(bool mine, uint32_t len, uint32_t& thr);
 template <bool WIDE, class Src>
-__device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len) {
+__device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len, uint64_t big,
+                                                uint32_t rank, uint32_t nact);
+
+// (RH_WIDE_SCHEMA, defined by specialize.cpp for a wide schema: copy_bytes is a real function there, called once per string
+//  column instead of inlined into every one of them -- the emit kernel of a 200-column schema compiles in 36 s instead of 88 s,
+//  for a call per column and wavefront)
+#ifdef RH_WIDE_SCHEMA
+#define RH_COPY_FN __attribute__((noinline))
+#else
+#define RH_COPY_FN __forceinline__
+#endif
+template <bool WIDE, class Src>
+__device__ RH_COPY_FN void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len, bool anylong) {
   // A store instruction costs the CU's store path about (width x 64 lanes) / 18 cycles WHATEVER the number of active
   // lanes (tools/storecost.hip): what a column costs that path is its bytes rounded up to pieces, whatever the piece.
 #ifndef RH_V_NOBATCH
@@ -261,7 +374,7 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
   // (the emit walk is bound by its dependent round trips at 16 waves per CU, not by instruction issue: 16 % fewer VALU
   // instructions moved it 1.5 %, profiles/r04d_*).  Then whole 8-byte pieces at constant offsets + the last 8 bytes,
   // overlapping; strings below 8 bytes by the set bits of their length.
-  if (!__any(len > 40u)) {
+  if (!anylong) {      // (wave-uniform: no string of the wave is longer than 40 bytes)
     const uint32_t sh = sp & 3u;
     uint32_t w0 = s.ld4a(sp), w1, w2, w3, w4, w5, w6, w7, w8, w9, w10;
     // (pieces the wave does not reach are never stored: their registers just need A value, at no cost)
@@ -308,7 +421,18 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
     return;
   }
 #endif
-  // longer strings in the wave: 16-byte pieces (two window reads in flight per round), 8..15 bytes as two overlapping
+  // longer strings in the wave.  The few longest ones first, by all the lanes that are active here (copy_bytes_coop) ...
+  if constexpr (!Src::kSlide) {
+    uint32_t thr;
+    const uint64_t big = pick_long(true, len, thr);
+    if (big) {
+      const uint64_t actm = __ballot(true);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(actm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)actm, 0u));
+      copy_bytes_coop<WIDE>(base, d, s, sp, len, big, rank, (uint32_t)__popcll(actm));
+      if (len >= thr) return;
+    }
+  }
+  // ... the others per lane: 16-byte pieces (two window reads in flight per round), 8..15 bytes as two overlapping
   // 8-byte stores, shorter ones by the set bits of their length
   if (len >= 16) {
     uint32_t j = 0;
@@ -335,6 +459,48 @@ __device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::ty
     if (len & 4u) st_at<u32u, WIDE>(base, d, (uint32_t)x);
     if (len & 2u) st_at<u16u, WIDE>(base, d + (len & 4u), (uint16_t)(x >> (8 * (len & 4u))));
     if (len & 1u) st_at<uint8_t, WIDE>(base, d + (len & 6u), (uint8_t)(x >> (8 * (len & 6u))));
+  }
+}
+
+template <bool WIDE, class Src>
+__device__ __forceinline__ void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len) {
+  copy_bytes<WIDE>(base, d, s, sp, len, __any(len > 40u));
+}
+
+// Long strings, by the whole wavefront (round 6): a lane that copies an 8 KiB string by itself runs 256 rounds of two 16-byte
+// pieces while its 63 neighbours wait; here the strings of `big` (a ballot: few lanes, each with at least kCoopMin bytes) are
+// taken one after the other, lane i copying the 16-byte pieces i, i + 64, ... -- 1 KiB per round, the last piece drawn back to
+// end with the string (overlapping, like copy_bytes' tails).  Over a SlideSrc (the ranged kernels: a record of its own may hold
+// ONE string of megabytes, with one lane active) h_string calls it outside its per-lane region, all 64 lanes taking part; the
+// kernels of the tiles that fit call it from copy_bytes' long-string branch, inside the region, with the lanes that are active
+// there -- the common path (no string beyond 40 bytes) pays nothing for it.
+// pick_long: the smallest threshold (256 B, 1 KiB, 4 KiB ...) that leaves at most kCoopMaxLanes strings to the wavefront, so that
+// the per-lane rounds end where many lanes are still busy; 0 = nothing for the wavefront.
+constexpr uint32_t kCoopMin = 256;
+constexpr uint32_t kCoopMaxLanes = 16;
+__device__ __forceinline__ uint64_t pick_long(bool mine, uint32_t len, uint32_t& thr) {
+  thr = kCoopMin;
+  uint64_t big = __ballot(mine && len >= thr);
+  while ((uint32_t)__popcll(big) > kCoopMaxLanes && thr < (1u << 20)) { thr <<= 2; big = __ballot(mine && len >= thr); }
+  return (uint32_t)__popcll(big) > kCoopMaxLanes ? 0ull : big;
+}
+// `rank` of `nact`: this lane's place among the lanes that take part (all 64, or -- inside a per-lane region -- the active ones).
+template <bool WIDE, class Src>
+__device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len, uint64_t big,
+                                                uint32_t rank, uint32_t nact) {
+  while (big) {
+    const int j = (int)__builtin_ctzll(big);
+    big &= big - 1;
+    const uint32_t sp_j = (uint32_t)__builtin_amdgcn_readlane((int)sp, j);
+    const uint32_t ln_j = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
+    typename BufOff<WIDE>::type d_j;
+    if constexpr (WIDE) d_j = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)d >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, j);
+    else d_j = (uint32_t)__builtin_amdgcn_readlane((int)d, j);
+    for (uint32_t off = rank * 16u; off < ln_j; off += nact * 16u) {
+      const uint32_t o = off + 16u <= ln_j ? off : ln_j - 16u;
+      const v4w x = s.ld16(sp_j + o);
+      st_at<v4wu, WIDE>(base, d_j + o, x);
+    }
   }
 }
 
@@ -462,8 +628,24 @@ __device__ __forceinline__ bool varint35(uint64_t y, uint32_t avail, uint32_t& v
   return (e4 & 0x80u) == 0 && n <= avail;
 }
 
+// (A/B knobs, scripts/gpu_ab.sh: RH_V_INT28 = the 4-byte int form of rounds 1-5, RH_V_LEN16 = lengths / counts in the 2-byte form)
+__device__ __forceinline__ bool varint32(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
+  const uint32_t t = ~y & 0x80808080u;
+  n = (uint32_t)(__ffs((int)t) + 7) >> 3;
+  y &= t ^ (t - 1);
+  y = ((y & 0x7F007F00u) >> 1) | (y & 0x007F007Fu);
+  raw = ((y & 0x3FFF0000u) >> 2) | (y & 0x00003FFFu);
+  return t != 0 && n <= avail;
+}
+
 // length / block count: raw (pre-zigzag) value and byte length of a varint of <= 3 bytes at bit 0 of y
 __device__ __forceinline__ bool varint24(uint32_t y, uint32_t avail, uint32_t& raw, uint32_t& n) {
+#ifdef RH_V_LEN16
+  const uint32_t m = (uint32_t)((int32_t)(y << 24) >> 31);
+  raw = ((((y >> 8) & 0x7Fu) & m) << 7) | (y & 0x7Fu);
+  n = 1u - m;
+  return (y & 0x8080u) != 0x8080u && n <= avail;
+#endif
   const uint32_t m0 = (uint32_t)((int32_t)(y << 24) >> 31);          // all ones when byte 0 carries a continuation flag
   const uint32_t m1 = (uint32_t)((int32_t)(y << 16) >> 31) & m0;     // ... and byte 1 too
   raw = (y & 0x7Fu) | ((((y >> 8) & 0x7Fu) & m0) << 7) | ((((y >> 16) & 0x7Fu) & m1) << 14);
@@ -563,7 +745,11 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
   else if constexpr ((LA & 2) != 0 && (LA >> 2) == 8) x = src.ld8(L.cur);
   else if constexpr ((LA & 2) != 0) x = (uint64_t)src.ld4(L.cur);
   else if (want_varint && wide) src.ld12(L.cur, x, xh);
+#ifdef RH_V_INT28
+  else x = (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : src.ld5(L.cur);
+#else
   else x = (narrow || (kNarrow && !want_varint)) ? (uint64_t)src.ld4(L.cur) : nullable ? src.ld8(L.cur) : src.ld5(L.cur);
+#endif
   // The fast size walk (neither careful nor trusted) checks a record's bounds ONCE, at its end (spec_size: cursor past
   // the record's end -> the wave is walked again, carefully): a cursor only ever moves forward, so a read that runs past
   // the end leaves it past the end for good, and what such a lane decodes meanwhile is never used.  No compare against
@@ -599,9 +785,15 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
         v = (int64_t)(int32_t)((raw >> 1) ^ (0u - (raw & 1u)));
       }
     } else {
+#ifdef RH_V_INT28
+      uint32_t raw;
+      okv = varint32((uint32_t)y, av, raw, n);
+      v = (int64_t)(int32_t)((raw >> 1) ^ (0u - (raw & 1u)));
+#else
       uint32_t v32;
       okv = varint35(y, av, v32, n);
       v = (int64_t)(int32_t)v32;
+#endif
     }
   }
   const bool slow = dec && (!okb || (isval && !okv));
@@ -636,6 +828,9 @@ __device__ __forceinline__ bool read_head(const Src& src, Lane& L, bool dec, boo
 //   void set_bit(int buf, int dom, uint32_t row) set one bit of a CHILD-domain bitmap (rows there do not line up with lanes)
 //   void put_word0(int buf, uint64_t m)          this wavefront's 64 bits of a DOMAIN-0 bitmap (rows == lanes: a ballot)
 //   lrow, lane, wave_live, sym_off, sym_data
+//   kWaveCtr / wave_total(id, len) / wave_offset(id, len)   wide schemas (program.h F_WAVE_CTR): the byte counter of a domain-0
+//       column has no per-lane state -- the size walk adds the wavefront's sum of `len` to the tile's total of counter id, the
+//       emit walk returns this lane's chunk-relative byte offset (the wavefront's running base + the exclusive scan of `len`)
 // --------------------------------------------------------------------------
 template <class Ctx>
 __device__ __forceinline__ uint32_t row_of(const Ctx& c, int dom) {
@@ -650,6 +845,9 @@ struct SkipCtx {
   static constexpr bool kSkip = true;
   static constexpr bool kWide = C::kWide;
   static constexpr bool kEnumImm = C::kEnumImm;
+  static constexpr bool kWaveCtr = false;             // (the bodies of lists hold per-lane counters only)
+  __device__ __forceinline__ void wave_total(int, uint32_t) const {}
+  __device__ __forceinline__ uint32_t wave_offset(int, uint32_t) const { return 0; }
   static __device__ __forceinline__ bool enum_sym(int b, uint32_t v, uint32_t& len, uint64_t& bits) { return C::enum_sym(b, v, len, bits); }
   const C& base;
   const uint32_t* sym_off;
@@ -663,22 +861,24 @@ struct SkipCtx {
   // (the EMIT side of the handlers is dead code under EMIT = false, but it has to compile)
   __device__ __forceinline__ void* buf(int id) const { return base.buf(id); }
   __device__ __forceinline__ uint32_t gbase(int id) const { return base.gbase(id); }
-  __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { base.add_nulls_wave(node, n); }
+  template <bool ACC> __device__ __forceinline__ void add_nulls_wave(int node, uint32_t n) const { base.template add_nulls_wave<ACC>(node, n); }
   __device__ __forceinline__ void add_nulls_lane(int node) const { base.add_nulls_lane(node); }
-  __device__ __forceinline__ void put_word0(int b, uint64_t m) const { base.put_word0(b, m); }
+  template <bool ACC> __device__ __forceinline__ void put_word0(int b, uint64_t m) const { base.template put_word0<ACC>(b, m); }
   __device__ __forceinline__ void set_bit(int b, int dom, uint32_t row) const { base.set_bit(b, dom, row); }
 };
 
 // validity bit + null count of one row (the buffer exists iff F_CAN_NULL)
-template <bool EMIT, class Ctx>
+// ACC (Src::kSlide): a wavefront may walk its records in several ranges (spec_body.h ranged_tile): its bitmap word and its
+// null count of a domain-0 field are then accumulated (OR / add onto zeroed words) instead of stored.
+template <bool EMIT, bool ACC = false, class Ctx>
 __device__ __forceinline__ void put_validity(const Ctx& c, const Op& op, bool act, bool valid, uint32_t row) {
   if (!EMIT) return;
   if (!(op.flags & F_CAN_NULL)) return;
   if (op.dom == 0) {   // rows == lanes: one ballot, one 64-bit store per wavefront
     const uint64_t m = __ballot(valid);
     const uint64_t nm = __ballot(act && !valid);
-    c.put_word0(op.buf0, m);
-    c.add_nulls_wave(op.node, (uint32_t)__popcll(nm));
+    c.template put_word0<ACC>(op.buf0, m);
+    c.template add_nulls_wave<ACC>(op.node, (uint32_t)__popcll(nm));
   } else if (act) {
     if (valid) c.set_bit(op.buf0, op.dom, row);
     else c.add_nulls_lane(op.node);
@@ -730,7 +930,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
     if (op.a == FK_BOOL) {
       if (op.dom == 0) {
         const uint64_t m = __ballot(bits != 0);
-        c.put_word0(op.buf1, m);
+        c.template put_word0<Src::kSlide>(op.buf1, m);
       } else if (act && bits) {
         c.set_bit(op.buf1, op.dom, row);
       }
@@ -739,7 +939,7 @@ __device__ __forceinline__ void h_fixed(const Ctx& c, const Src& src, Lane& L, c
       else st_global<uint64_t, Ctx::kWide>(pf1, row, bits);
     }
   }
-  put_validity<EMIT>(c, op, act, valid, row);
+  put_validity<EMIT, Src::kSlide>(c, op, act, valid, row);
 }
 
 // string leaf / map key (429, 454-457, 752, read_string 902-922) and enum -> symbol text (570-578)
@@ -784,21 +984,45 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
     }
   }
   const bool valid = want && L.live;
-  uint32_t& bo = c.counter(op.a);
-  const uint32_t o = bo;
+  // the byte counter: per lane (block-local after the emit kernel's scan), or -- wide schemas, domain 0 -- a wave counter
+  bool wctr = false;
+  if constexpr (Ctx::kWaveCtr) wctr = (op.flags & F_WAVE_CTR) != 0;
+  uint32_t o = 0;
+  if (wctr) {
+    if constexpr (EMIT) o = c.wave_offset(op.a, len);
+    else c.wave_total(op.a, len);
+  } else {
+    o = c.counter(op.a);
+  }
   uint32_t row = 0;
   if (EMIT) {
     row = row_of(c, op.dom);
+    // wave-uniform, outside the per-lane region: is any string of this column longer than copy_bytes' batched form takes, and
+    // which few of them are long enough for the whole wavefront to copy (copy_bytes_coop)
+    // (over a SlideSrc the long strings are picked here, outside the per-lane region: all 64 lanes copy them -- copy_bytes_coop)
+    bool anylong = false, coop = false;
+    uint64_t big = 0;
+    if constexpr (Src::kSlide) {
+      if (op.code == OP_STRING) {
+        anylong = __any(act && len > 40u);
+        if (anylong) {
+          uint32_t thr;
+          big = pick_long(act, len, thr);
+          coop = big != 0 && len >= thr;
+        }
+      }
+    }
+    const uint32_t gb = wctr ? 0u : c.gbase(op.a);                   // (a wave counter's offset is chunk-relative already)
     if (act) {
-      const uint32_t gb = c.gbase(op.a);
       st_global<uint32_t, Ctx::kWide>(pb1, row + 1, gb + o + len);   // offsets repeat under nulls
-      if (len) {
+      if (len && !coop) {
         // String bytes go straight to HBM with per-lane 8-byte stores at any alignment: neighbouring lanes
         // own neighbouring rows, so one wave store covers one contiguous span of the column.  (Staging the
         // column in LDS and flushing it with aligned 16-byte stores was measured slower: the extra LDS halves
         // the workgroups per CU, and this walk is latency-bound -- DESIGN.md, "string bytes".)
         if (op.code == OP_STRING) {
-          copy_bytes<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
+          if constexpr (Src::kSlide) copy_bytes<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len, anylong);
+          else copy_bytes<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len);
         } else {
           if (sym_imm) {
             store_reg8<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, sym_bits, len);
@@ -809,9 +1033,12 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
         }
       }
     }
+    if constexpr (Src::kSlide) {
+      if (big) copy_bytes_coop<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len, big, c.lane, 64u);
+    }
   }
-  bo = o + len;   // len == 0 for every lane that does not carry a value
-  put_validity<EMIT>(c, op, act, valid, row);
+  if (!wctr) c.counter(op.a) = o + len;   // len == 0 for every lane that does not carry a value
+  put_validity<EMIT, Src::kSlide>(c, op, act, valid, row);
 }
 
 // --------------------------------------------------------------------------
@@ -926,7 +1153,7 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
       }
     }
   }
-  put_validity<EMIT>(c, op, act, valid, row);
+  put_validity<EMIT, Src::kSlide>(c, op, act, valid, row);
 }
 
 // NullableRecord (482-485 + 595-616): a null record null-fills its children
@@ -938,7 +1165,7 @@ __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& 
   int64_t dummy = 0;
   const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
-  put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
+  put_validity<EMIT, Src::kSlide>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.pres = valid;
 }
 __device__ __forceinline__ void h_rec_end(Lane& L) {
@@ -981,7 +1208,7 @@ __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane&
   int64_t dummy = 0;
   const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
   const bool valid = isval && L.live;
-  put_validity<EMIT>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
+  put_validity<EMIT, Src::kSlide>(c, op, act, valid, EMIT ? row_of(c, op.dom) : 0);
   L.live = valid;      // only rows that really carry a list enter the block loop
   L.pres = valid;
   c.remaining(op.c) = 0;
@@ -1020,6 +1247,7 @@ __device__ __forceinline__ void list_next_slow(const Ctx& c, const Src& src, Lan
 // Head of the block loop.  Returns true while any lane of the wave still has an item (wave-uniform).
 template <bool CAREFUL, bool TRUST = false, class Src, class Ctx>
 __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  if constexpr (Src::kSlide) src.refill(L, c.lane);          // a record larger than the window: move the window up to the cursor
   uint32_t& rm = c.remaining(op.c);
   if constexpr (!CAREFUL && !TRUST) L.live = L.live && !L.redo;      // a lane that has met an anomaly (RH_REJECT_SOFT) stops iterating here
   const bool need = L.live && rm == 0;            // this lane is at a block boundary

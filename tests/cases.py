@@ -411,3 +411,108 @@ def dense_list_cases():
              "k": i} for i in range(530)]
     out.append(("dense_nullable_and_n4", s3, _enc(s3, vals)))
     return out
+
+
+def wide_form_cases():
+    """Round 6: values at both edges of every single-read wire form of the fast walk (walk.h: int <= 5
+    bytes, long <= 10 bytes also behind a branch byte, length / block count <= 3 bytes, index <= 2 bytes) -- what production data
+    carries where the benchmark generator does not: microsecond timestamps, epoch seconds as int, snowflake ids, strings of 8 KiB,
+    arrays of more than 8,191 items.  Whole wavefronts stay inside the forms (the first 640 records are small: their tiles take the
+    staged fast walk), the tail holds the large values (over-window tiles).  -> list of (name, schema_json, records)."""
+    out = []
+    s = json.dumps({"type": "record", "name": "WF", "fields": [
+        {"name": "ni", "type": ["null", "int"]}, {"name": "i", "type": "int"},
+        {"name": "nl", "type": ["null", "long"]}, {"name": "l", "type": "long"},
+        {"name": "ts", "type": [{"type": "long", "logicalType": "timestamp-micros"}, "null"]},
+        {"name": "s", "type": "string"}, {"name": "ns", "type": ["null", "string"]},
+        {"name": "arr", "type": {"type": "array", "items": "string"}},
+        {"name": "ai", "type": {"type": "array", "items": "int"}},
+        {"name": "e", "type": {"type": "enum", "name": "WE", "symbols": ["x", "yy", "zzz"]}},
+        {"name": "u", "type": ["null", "string", "int", "long"]},
+        {"name": "tail", "type": "boolean"}]})
+    ints = [0, 63, -64, 64, -65, 8191, -8192, 8192, 2**20 - 1, 2**20, -2**20 - 1, 2**27 - 1, -2**27, 2**27, 2**31 - 1, -2**31,
+            1_750_000_000, -1_750_000_000, -1]
+    longs = [0, 2**27, 2**34 - 1, 2**34, 2**41, 2**48 - 1, 2**48, -2**48 - 1, 2**55 - 1, 2**55, -2**55 - 1, 2**62 - 1, 2**62,
+             -2**62 - 1, 2**63 - 1, -2**63, 1_750_000_000_000_000, 1_934_000_000_000_000_000, -1]
+    vals = []
+    for r in range(700):
+        big = r >= 640
+        sl = [0, 1, 7, 8, 40, 41, 63, 64][r % 8] if not big else [8191, 8192, 8193, 20000, 70000, 2**20 - 1, 2**20, 300][r % 8]
+        na = r % 4 if not big else [8191, 8192, 10000, 3][r % 4]
+        vals.append({"ni": None if r % 5 == 0 else ints[r % len(ints)], "i": ints[(r * 7) % len(ints)],
+                     "nl": None if r % 7 == 0 else longs[r % len(longs)], "l": longs[(r * 5) % len(longs)],
+                     "ts": None if r % 11 == 0 else 1_750_000_000_000_000 + r * 1_000_003,
+                     "s": chr(97 + r % 26) * sl, "ns": None if r % 3 == 0 else "N" * (sl // 3),
+                     "arr": [f"a{r}.{j}" for j in range(na)], "ai": [ints[(r + j) % len(ints)] for j in range(na if na < 100 else 8200)],
+                     "e": ["x", "yy", "zzz"][r % 3],
+                     "u": [None, f"u{r}", ints[r % len(ints)], Branch(3, longs[r % len(longs)])][r % 4], "tail": r % 2 == 0})
+    out.append(("wide_forms", s, _enc(s, vals)))
+
+    # the same widths as PADDED encodings of small values (legal: fast_decode.rs:854-869 takes any continuation chain of up to 10
+    # bytes), at and one byte beyond every form's width: the value is the same, which walk decodes it differs
+    def padded(v: int, width: int) -> bytes:
+        z = ((v << 1) ^ (v >> 63)) & ((1 << 64) - 1)
+        b = bytearray()
+        for k in range(width):
+            b.append((z & 0x7F) | (0x80 if k < width - 1 else 0))
+            z >>= 7
+        assert z == 0
+        return bytes(b)
+    s2 = json.dumps({"type": "record", "name": "WP", "fields": [
+        {"name": "ni", "type": ["null", "int"]}, {"name": "nl", "type": ["null", "long"]},
+        {"name": "ns", "type": ["null", "string"]}, {"name": "arr", "type": {"type": "array", "items": "int"}},
+        {"name": "e", "type": {"type": "enum", "name": "PE", "symbols": ["x", "yy", "zzz"]}}]})
+    raw = []
+    for r in range(200):
+        wi = [1, 4, 5, 6, 5][r % 5]          # int: 5 is the form's width, 6 beyond it
+        wl = [1, 8, 9, 10, 10][r % 5]        # long: all inside the 10-byte form
+        ws = [1, 2, 3, 4, 3][r % 5]          # length: 3 inside, 4 beyond
+        wc = [1, 2, 3, 4, 2][r % 5]          # block count
+        we = [1, 2, 3, 2, 1][r % 5]          # index: 2 inside, 3 beyond
+        only_fast = r < 128                  # two wavefronts that never leave the forms
+        if only_fast:
+            wi, ws, wc, we = min(wi, 5), min(ws, 3), min(wc, 3), min(we, 2)
+        rec = b"\x02" + padded(-(r + 1) * 1000 if r % 2 else r * 77, max(wi, 3))
+        rec += b"\x02" + padded((r - 100) * (1 << 33), max(wl, 6))
+        rec += b"\x02" + padded(3, ws) + b"abc"
+        rec += padded(2, wc) + padded(r, 2) + padded(-r, 2) + padded(0, wc)
+        rec += padded(r % 3, we)
+        raw.append(rec)
+    # ten-byte longs whose tenth byte carries more than bit 0 (the reference drops those bits: `<< 63`), an eleventh byte is an error
+    raw.append(b"\x02\x00" + b"\x02" + b"\xff" * 9 + b"\x7f" + b"\x00" + b"\x00" + b"\x00")
+    raw.append(b"\x02\x00" + b"\x02" + b"\x80" * 9 + b"\x01" + b"\x00" + b"\x00" + b"\x00")
+    out.append(("padded_at_form_widths", s2, raw))
+    return out
+
+
+def giant_record_cases():
+    """Round 6: records far larger than any LDS window between ordinary ones -- arrays of tens of
+    thousands of strings / ints / nullable records (child-domain bitmaps), a map, a nested array, megabyte strings in front of and
+    behind them -- so that a tile holds ranges that fit, ranges of one sliding record, and ordinary records again.
+    -> list of (name, schema_json, records)."""
+    out = []
+    s = json.dumps({"type": "record", "name": "G", "fields": [
+        {"name": "id", "type": "long"},
+        {"name": "pre", "type": ["null", "string"]},
+        {"name": "tags", "type": {"type": "array", "items": "string"}},
+        {"name": "nums", "type": {"type": "array", "items": ["null", "int"]}},
+        {"name": "recs", "type": {"type": "array", "items": {"type": "record", "name": "GI", "fields": [
+            {"name": "k", "type": "string"}, {"name": "v", "type": ["null", "long"]}, {"name": "f", "type": "boolean"}]}}},
+        {"name": "m", "type": {"type": "map", "values": "int"}},
+        {"name": "nest", "type": {"type": "array", "items": {"type": "array", "items": "int"}}},
+        {"name": "post", "type": "string"}]})
+    vals = []
+    for r in range(420):
+        giant = r in (3, 64, 65, 200, 419)
+        n = [0, 1, 2, 5][r % 4]
+        if giant:
+            n = [30_000, 9_000, 70_000, 12_345, 40_000][(3, 64, 65, 200, 419).index(r)]
+        vals.append({"id": r * 1_000_003, "pre": None if r % 3 == 0 else ("P" * (1_200_000 if r == 200 else r % 50)),
+                     "tags": [f"tag-{r}-{j}" * (1 + j % 3) for j in range(n)],
+                     "nums": [None if (r + j) % 5 == 0 else j * 7 - r for j in range(n // 2)],
+                     "recs": [{"k": f"k{j}", "v": None if j % 3 == 0 else j * 1_000_000_007, "f": j % 2 == 0} for j in range(n // 3)],
+                     "m": [(f"key{j}", j) for j in range(n if n < 100 else 2_000)],
+                     "nest": [[j, j + 1, j + 2][: j % 4] for j in range(n if n < 100 else 5_000)],
+                     "post": "z" * (r % 20) if r != 65 else "Q" * 300_000})
+    out.append(("giant_arrays", s, _enc(s, vals)))
+    return out
