@@ -441,6 +441,17 @@ def run(args, make_step=None, backend="nccl"):
         dev = torch.device("cpu")
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):      # (BENCH_FORCE_DIST: a one-rank RCCL group, to test the plumbing on one GPU)
         rdist.init_process_group(backend, dev if use_cuda else None)
+    # Multi-GPU readiness: the launcher's world, the process group's world and --gpus must be ONE
+    # number, and every rank must see a device of its own -- a mis-launched run fails here, loudly, instead of printing a line
+    # whose n_gpus says one thing while a different number of GPUs worked.
+    if getattr(args, "gpus", world) != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: launch N ranks with torch.distributed.run --nproc-per-node N")
+    if dist.is_initialized() and dist.get_world_size() != world:
+        raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
+    if use_cuda:
+        visible = torch.cuda.device_count()
+        if visible < 1 or local_rank >= visible:
+            raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) sees {visible} GPU(s): one process per GPU needs LOCAL_RANK < visible devices")
 
     gen_cfg, n, num_chunks, desc = WORKLOADS[args.workload]
     if args.records:

@@ -211,8 +211,12 @@ int rh_decode_device(const rh_schema* s, const void* d_data, const void* d_offse
   return guarded(err, [&] {
     require_device();
     Timer t;
+    // (the engine keeps bits of its own in rh_opts.flags -- RH_INTERNAL_*; a caller's stray high bits must not
+    //  turn a device result into a pinned-host one or force a launch form: only the documented bits pass the C ABI)
+    rh_opts pub;
+    if (opts) { pub = *opts; pub.flags &= kPublicFlags; }
     *out = decode_device_impl(const_cast<rh_schema*>(s), (const uint8_t*)d_data, (const uint64_t*)d_offsets, data_len,
-                              n, num_chunks, opts, stats);
+                              n, num_chunks, opts ? &pub : nullptr, stats);
     if (stats) stats->total_ms = t.ms();
     return RH_OK;
   });

@@ -344,7 +344,9 @@ struct rh_decode_call {
     const uint64_t o_bbase = align_up(o_bsum + 4ull * K * nblocks, kAlign);
     const uint64_t o_flag = align_up(o_bbase + 4ull * K * nblocks, kAlign);
     const uint64_t o_lcnt = align_up(o_flag + 4ull * nblocks, kAlign);
-    const uint64_t ws_bytes = align_up(o_lcnt + (sk ? 4ull * ((cs.KL + 1) / 2) * nblocks * tile : 0), kAlign);
+    // (per-record counters from the size pass to the emit pass: two per dword for the specialised kernels, one for the generic ones)
+    const uint64_t o_lcnt32 = align_up(o_lcnt + 4ull * (sk ? (uint64_t)((cs.KL + 1) / 2) : (uint64_t)cs.KL) * nblocks * tile, kAlign);
+    const uint64_t ws_bytes = align_up(o_lcnt32 + ((size_r && emit_r) ? 4ull * (uint64_t)cs.KL * nblocks * tile : 0), kAlign);      // (+ the ranged pair's 32-bit counters)
     hp.mark("setup");
     ws = Lease(dev_pool(), ws_bytes, device);
     hctrl = Lease(pin_pool(), ctrl_bytes, device);
@@ -368,6 +370,7 @@ struct rh_decode_call {
     P.blockbase = (uint32_t*)(ws.ptr() + o_bbase);
     P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
     P.lanecnt = (uint32_t*)(ws.ptr() + o_lcnt);
+    P.lanecnt32 = (uint32_t*)(ws.ptr() + o_lcnt32);
 
     // LDS: fixed part + input window sized from the mean record length (falls back to global reads
     // for workgroups whose 256 records do not fit)
@@ -390,6 +393,14 @@ struct rh_decode_call {
       for (uint64_t nwg = 4; nwg >= 2; nwg--) {        // (4: what the emit kernel's registers allow at most)
         const uint64_t step = (160 * 1024 / nwg) & ~511ull;
         if (lds_fixed + win > step && step > lds_fixed && step - lds_fixed >= min_win) { win = (step - lds_fixed) & ~15ull; break; }
+      }
+      // Round 6: never a window that leaves a CU fewer than four workgroups.  Records too large for it (a mean tile of 40 KB and
+      // more: ~150 B per record) are walked in ranges by the ranged kernels, which keeps sixteen wavefronts per CU resident --
+      // measured on the skewed workload (mean record 393 B): 7.1 ms with a 40 KB window, 10.7 ms with the 100 KB one the mean
+      // tile asks for (profiles/r06_c_*).  Only with the specialised kernels: the generic ones have no ranges.
+      if (sk && !cs.wide) {
+        const uint64_t step4 = (160 * 1024 / 4) & ~511ull;
+        if (step4 > lds_fixed + 8192 && lds_fixed + win > step4) win = (step4 - lds_fixed) & ~15ull;
       }
     }
     // A wide schema's tile is one wavefront: the window is kept small enough for 8 of them per CU (records of a hundred and more

@@ -342,13 +342,15 @@ struct SpecKernel {      // schema-specialised kernels loaded on one device (eac
   // the ranged pair (tiles past the LDS window, spec_body.h ranged_tile): compiled and loaded when the schema first meets such
   // tiles; both or neither (emit_r_fn is stored last)
   std::atomic<hipFunction_t> size_r_fn{nullptr}, emit_r_fn{nullptr};
-  bool ranged_dead = false;
+  std::atomic<bool> ranged_dead{false};
   // the single-pass form (decode kernels only): compiled and loaded when a call first asks for it, so it is written while
   // other calls of the schema read it
   std::atomic<hipFunction_t> fused_fn{nullptr};
-  bool fused_dead = false;  // no such kernel for this schema (K > 64), or its compile failed
-  bool ok = false;          // size_fn and emit_fn are loaded
-  bool dead = false;        // they never will be: `why` says why (a failure is remembered)
+  // (atomics: callers read these from the reference spec_kernel() returns, without the schema's mutex, while another thread of
+  //  the same schema and device may be loading a kernel -- ADVICE round 5; `why` is only read once `dead` is seen set)
+  std::atomic<bool> fused_dead{false};  // no such kernel for this schema (K > 64), or its compile failed
+  std::atomic<bool> ok{false};          // size_fn and emit_fn are loaded
+  std::atomic<bool> dead{false};        // they never will be: `why` says why (a failure is remembered)
   std::string why;
 };
 
@@ -572,6 +574,7 @@ void settle(rh_device_result* r);
 // ---------------------------------------------------------------------------
 // integer knob from the environment, read at every use (tests change them inside one process); out of range = default
 constexpr long kSinglePassDefault = 0;           // RUHVRO_HIP_SINGLE_PASS: 1 = every qualifying call prefers the single-pass form (else RH_SINGLE_PASS per call)
+constexpr int kPublicFlags = 3 | RH_ASYNC | RH_TWO_PASS | RH_SINGLE_PASS;      // the rh_opts.flags bits of include/ruhvro_hip.h
 constexpr int RH_INTERNAL_HOST_ARENA = 0x200;    // rh_opts.flags, engine-internal (host calls): write the Arrow buffers straight into pinned host memory if a pooled block is free
 constexpr int RH_INTERNAL_TWO_PASS = 0x100;      // rh_opts.flags, engine-internal: this call must take the two-pass path
 constexpr long kInternalStreamsDefault = 1;      // RUHVRO_HIP_INTERNAL_STREAMS (decode_device_split)

@@ -35,8 +35,20 @@ int main(int argc, char** argv) {
   }
   const std::string src_path = argv[1], out = argv[2], err = argv[3];
   const std::string lock = out + ".lock";
-  const int lfd = ::open(lock.c_str(), O_CREAT | O_RDWR, 0644);
-  if (lfd >= 0) (void)::flock(lfd, LOCK_EX);        // (no lock, e.g. a file system without flock: compile anyway)
+  // (no lock, e.g. a file system without flock: compile anyway.)  The holder unlinks the lock file when it is done, so a waiter
+  // may wake up holding a lock on an inode that is no longer at the path while a later arrival locks a NEW file there: after
+  // flock, the descriptor must still be the file at the path, else open again (after a failed compile several
+  // helpers used to compile the same object at once).
+  int lfd = -1;
+  for (int tries = 0; tries < 64; tries++) {
+    lfd = ::open(lock.c_str(), O_CREAT | O_RDWR, 0644);
+    if (lfd < 0) break;
+    if (::flock(lfd, LOCK_EX) != 0) break;
+    struct stat a, b;
+    if (::fstat(lfd, &a) == 0 && ::stat(lock.c_str(), &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev) break;
+    ::close(lfd);
+    lfd = -1;
+  }
   int rc = 0;
   if (!present(out)) {
     try {

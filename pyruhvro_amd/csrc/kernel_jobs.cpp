@@ -19,6 +19,8 @@
 #include <set>
 #include <thread>
 
+#include <dirent.h>
+
 #include "rtc_compile.h"
 
 extern char** environ;
@@ -44,6 +46,8 @@ struct Registry {
   unsigned in_process = 0;       // of which compile inside this process (hiprtc on a job thread)
   bool exiting = false;
   bool hooked = false;
+  std::string priv_dir;          // work_dir()'s private directory of this process (read-only kernel cache), removed at exit
+  std::set<std::string> scratch; // <object>.<pid>.<n>.src / .err files of helpers in flight: removed at exit when their helper is killed
 };
 Registry& registry() {
   static Registry* r = new Registry;
@@ -68,13 +72,29 @@ unsigned max_jobs() {
 
 // At exit: helper processes are killed (their output is only ever renamed into place when complete); a compile that runs
 // inside this process cannot be interrupted and LLVM must not be torn down under it, so exit waits for those.
+// (the killed helpers' scratch files and a private work directory used to stay behind; the wait for an
+//  in-process compile -- only without the helper program -- is bounded by RUHVRO_HIP_EXIT_WAIT_S, default 60 s.)
 void at_exit() {
   Registry& r = registry();
   std::unique_lock<std::mutex> g(r.mu);
   r.exiting = true;
   for (pid_t p : r.children) ::kill(p, SIGKILL);
   r.cv.notify_all();
-  r.cv.wait_for(g, std::chrono::seconds(180), [&] { return r.in_process == 0; });
+  long wait_s = 60;
+  if (const char* e = std::getenv("RUHVRO_HIP_EXIT_WAIT_S")) { const long v = std::atol(e); if (v >= 0 && v <= 3600) wait_s = v; }
+  r.cv.wait_for(g, std::chrono::seconds(wait_s), [&] { return r.in_process == 0; });
+  for (pid_t p : r.children) { int st = 0; (void)::waitpid(p, &st, 0); }      // reaped: nothing writes the files below any more
+  for (const std::string& f : r.scratch) { std::remove(f.c_str()); std::remove((f + ".err").c_str()); }
+  if (!r.priv_dir.empty()) {
+    if (DIR* d = ::opendir(r.priv_dir.c_str())) {
+      while (dirent* e = ::readdir(d)) {
+        if (!std::strcmp(e->d_name, ".") || !std::strcmp(e->d_name, "..")) continue;
+        std::remove((r.priv_dir + "/" + e->d_name).c_str());
+      }
+      ::closedir(d);
+    }
+    ::rmdir(r.priv_dir.c_str());
+  }
 }
 
 bool read_file(const std::string& path, std::vector<char>& out) {
@@ -127,7 +147,13 @@ std::string work_dir() {
     std::string tmpl = std::string(t && *t ? t : "/tmp") + "/ruhvro_hip_kcache.XXXXXX";
     std::vector<char> b(tmpl.begin(), tmpl.end());
     b.push_back(0);
-    if (::mkdtemp(b.data())) priv = b.data();
+    if (::mkdtemp(b.data())) {
+      priv = b.data();
+      Registry& r = registry();
+      std::lock_guard<std::mutex> rg(r.mu);
+      r.priv_dir = priv;
+      if (!r.hooked) { r.hooked = true; std::atexit(at_exit); }
+    }
   }
   return priv;
 }
@@ -151,7 +177,7 @@ bool run_helper(const std::string& helper, const std::string& source, const std:
     std::lock_guard<std::mutex> g(r.mu);     // (spawn and registration in one step: at_exit sees every child)
     if (r.exiting) { std::remove(src_path.c_str()); why = "process is exiting"; return false; }
     rc = ::posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv, environ);
-    if (rc == 0) r.children.insert(pid);
+    if (rc == 0) { r.children.insert(pid); r.scratch.insert(src_path); }
   }
   if (rc != 0) {
     std::remove(src_path.c_str());
@@ -164,6 +190,7 @@ bool run_helper(const std::string& helper, const std::string& source, const std:
   {
     std::lock_guard<std::mutex> g(r.mu);
     r.children.erase(pid);
+    r.scratch.erase(src_path);
   }
   std::remove(src_path.c_str());
   // (w < 0: somebody else reaped the child -- a host with SIGCHLD ignored, a blanket wait(); its files tell the outcome)

@@ -14,7 +14,7 @@
 //           workgroup's base row / base byte per counter, and chunk totals
 //           (= Arrow buffer sizes).
 //   k_init  offsets[0] = 0, zero the bitmaps written with atomics.
-//   k_emit  recomputes the counters of its 256 records, scans them inside the
+//   k_emit  takes the counters of its 256 records as k_size left them, scans them inside the
 //           workgroup, then walk 2 writes every Arrow buffer: values and
 //           offsets at [row] (coalesced), validity / boolean bitmaps with one
 //           64-bit ballot store per wavefront, sparse-union type ids, string
@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+
+#define RH_DEEP 1      // the interpreter takes any nesting the schema front-end accepts (walk.h stk_t / sel_t)
 
 #include "kernel_common.h"
 #include "program.h"
@@ -87,7 +89,8 @@ struct ICtx {
 // --------------------------------------------------------------------------
 // the interpreter: scalar program counter, one handler call per op
 // --------------------------------------------------------------------------
-template <bool EMIT, class Ctx, class Src>
+// (round 6: the interpreter walks fast or careful like the specialised kernels -- walk.h `reject` -- instead of always careful)
+template <bool EMIT, bool CAREFUL, class Ctx, class Src>
 __device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& src, Lane& L) {
   int pc = 0;
   for (;;) {
@@ -95,24 +98,24 @@ __device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& 
     const Op op = P.prog[pc];
     switch (op.code) {
       case OP_END: return;
-      case OP_FIXED: h_fixed<EMIT, true>(c, src, L, op); break;
+      case OP_FIXED: h_fixed<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_STRING:
-      case OP_ENUM: h_string<EMIT, true>(c, src, L, op); break;
-      case OP_REC_BEGIN: h_rec_begin<EMIT, true>(c, src, L, op); break;
+      case OP_ENUM: h_string<EMIT, CAREFUL>(c, src, L, op); break;
+      case OP_REC_BEGIN: h_rec_begin<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_REC_END: h_rec_end(L); break;
-      case OP_UNION_BEGIN: h_union_begin<EMIT, true>(c, src, L, op); break;
+      case OP_UNION_BEGIN: h_union_begin<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_VARIANT: h_variant(L, op); break;
       case OP_UNION_END: h_union_end(L); break;
-      case OP_LIST_BEGIN: h_list_begin<EMIT, true>(c, src, L, op); break;
+      case OP_LIST_BEGIN: h_list_begin<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_LIST_NEXT:
-        if (!h_list_next<true>(c, src, L, op)) { pc = op.b; continue; }
+        if (!h_list_next<CAREFUL, (EMIT && !CAREFUL)>(c, src, L, op)) { pc = op.b; continue; }
         break;
       case OP_LIST_TAIL:
         h_list_tail(c, L, op);
         pc = op.b;
         continue;
       case OP_LIST_END: h_list_end<EMIT>(c, L, op); break;
-      case OP_BIN: h_bin<EMIT, true>(c, src, L, op); break;
+      case OP_BIN: h_bin<EMIT, CAREFUL>(c, src, L, op); break;
       default: return;
     }
     pc++;
@@ -164,14 +167,18 @@ extern "C" uint32_t rh_lds_fixed_bytes(int K, int KL, int tile, int list_depth, 
   return lds_fixed_words(K, KL, tile, list_depth, nnodes, nbuf) * 4;
 }
 
-template <bool EMIT, int T>
+// fits: the tile's window is staged in LDS; cursors become LDS byte addresses (walk.h LdsAbsSrc).  A tile past the window is
+// walked carefully, straight from global memory (this form has no ranges: spec_body.h ranged_tile is the specialised kernels').
+template <bool EMIT, bool CAREFUL, int T>
 __device__ __forceinline__ void run_walk(const KParams& P, const ICtx<T>& c, const Smem& s, Lane& L, bool fits, uint64_t wb16) {
   if (fits) {
-    LdsSrc src{s.win};
-    walk<EMIT>(P, c, src, L);
+    const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
+    L.cur += wa; L.end += wa;
+    LdsAbsSrc src;
+    walk<EMIT, CAREFUL>(P, c, src, L);
   } else {
     GlobalSrc src{P.data + wb16, P.data_len - wb16};
-    walk<EMIT>(P, c, src, L);
+    walk<EMIT, true>(P, c, src, L);
   }
 }
 
@@ -200,21 +207,39 @@ __device__ __forceinline__ void k_size_body(const KParams& P) {
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   if (fits) stage_window<T>(P, s.win, wb16, we, tid);
   for (int k = 0; k < P.KL; k++) s.cnt[k * T + tid] = 0;
-  if (tid == 0) s.misc[0] = 0xFFFFFFFFu;
+  if (tid == 0) { s.misc[0] = 0xFFFFFFFFu; s.misc[2] = 0; }
   __syncthreads();
 
   Lane L;
   lane_init(L, P, g, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;   // window beyond 32-bit cursors
   const ICtx<T> c = make_ctx<T>(P, s, g, tid);
-  run_walk<false>(P, c, s, L, fits, wb16);
+  uint32_t tflag = fits ? 0u : (uint32_t)(TF_OVER_WINDOW | TF_CAREFUL);
+  if (fits) {
+    // the fast walk; a wavefront with a record outside the fast wire forms (or malformed) walks again, carefully
+    run_walk<false, false>(P, c, s, L, true, wb16);
+    L.redo = L.redo || L.cur > L.end;
+    if (__any(L.redo)) {
+      tflag |= (uint32_t)(TF_CAREFUL | TF_REWALK_ONE);
+      for (int k = 0; k < P.KL; k++) s.cnt[k * T + tid] = 0;
+      for (int d = 0; d < P.list_depth; d++) s.rem[d * T + tid] = 0;
+      lane_init(L, P, g, wb16, tid);
+      run_walk<false, true>(P, c, s, L, true, wb16);
+    }
+  } else {
+    run_walk<false, true>(P, c, s, L, false, wb16);
+  }
+  if (lane == 0 && tflag) { atomicOr(&s.misc[2], tflag & ~(uint32_t)TF_REWALK_ONE); if (tflag & (uint32_t)TF_REWALK_ONE) atomicAdd(&s.misc[2], (uint32_t)TF_REWALK_ONE); }
 
+  // every record's per-lane counters -> HBM ([tile][counter][record]: coalesced), so that k_emit does not size again
   for (int k = 0; k < P.KL; k++) {
-    uint32_t v = wave_sum(s.cnt[k * T + tid]);
+    const uint32_t cv = s.cnt[k * T + tid];
+    P.lanecnt[((size_t)blockIdx.x * P.KL + k) * T + tid] = cv;
+    const uint32_t v = wave_sum(cv);
     if (lane == 0) s.wtot[k * NW + wave] = v;
   }
-  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot (and the wave counters' sums in wv)
-  if (tid == 0) P.tileflag[blockIdx.x] = fits ? 0u : (uint32_t)TF_OVER_WINDOW;      // (statistics only: this form always walks carefully)
+  report_errors(P, s.misc, L, g, tid, blockIdx.x);   // contains the barrier that publishes wtot, misc[2] (and the wave counters' sums in wv)
+  if (tid == 0) P.tileflag[blockIdx.x] = s.misc[2];
   for (int k = tid; k < P.K; k += T) {
     uint32_t t = 0;
     if (k < P.KL) { for (int w = 0; w < NW; w++) t += s.wtot[k * NW + w]; }
@@ -485,14 +510,15 @@ __device__ __forceinline__ void k_emit_body(const KParams& P) {
   Lane L;
   const ICtx<T> c = make_ctx<T>(P, s, g, tid);
 
+  // the size pass's verdict on this tile (no size pass -- K == 0 -- or RUHVRO_HIP_NO_TRUST: every tile carefully)
+  const bool careful = !fits || P.all_careful != 0 || (P.K > 0 && (P.tileflag[blockIdx.x] & (uint32_t)TF_CAREFUL) != 0);
   if (P.K > 0) {
-    // walk 1 again (cheaper than 4*K bytes/record of HBM round trip), then the in-workgroup scan of the per-lane counters
-    // (the wave counters of a wide schema need neither: ICtx::wave_offset scans them on the spot in walk 2)
+    // the per-lane counters as k_size left them (round 6: 4 bytes per counter and record each way instead of a second size
+    // walk -- the interpreter's walk costs ~100 instructions per op), then the in-workgroup scan
+    // (the wave counters of a wide schema need neither: ICtx::wave_offset scans them on the spot in the emit walk)
     if (P.KL > 0) {
-      lane_init(L, P, g, wb16, tid);
-      run_walk<false>(P, c, s, L, fits, wb16);
       for (int k = 0; k < P.KL; k++) {
-        const uint32_t v = s.cnt[k * T + tid];
+        const uint32_t v = P.lanecnt[((size_t)blockIdx.x * P.KL + k) * T + tid];
         const uint32_t incl = wave_incl_scan(v, lane);
         if (lane == 63) s.wtot[k * NW + wave] = incl;
         s.cnt[k * T + tid] = incl - v;
@@ -516,7 +542,12 @@ __device__ __forceinline__ void k_emit_body(const KParams& P) {
 
   lane_init(L, P, g, wb16, tid);
   if (L.live && (we - wb16) > 0xFFFFFFF0ull) L.err = E_EOB;
-  run_walk<true>(P, c, s, L, fits, wb16);
+  if (careful) {
+    run_walk<true, true>(P, c, s, L, fits, wb16);
+  } else {
+    run_walk<true, false>(P, c, s, L, true, wb16);     // (trusted: the size pass met no anomaly in this tile)
+    if (L.redo) L.err = E_INTERNAL;
+  }
 
   report_errors(P, s.misc, L, g, tid, blockIdx.x);   // barrier inside: nullcnt + staging complete
   for (int i = tid; i < P.nnodes; i += T) {

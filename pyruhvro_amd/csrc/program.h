@@ -28,9 +28,14 @@ namespace rh {
 constexpr int kBlock = 256;          // threads (= records) per workgroup
 constexpr int kWideCounters = 64;    // schemas with more scanned counters (row domains + byte columns) are compiled WIDE: no limit on their number
 constexpr int kWideTile = 64;        // ... records per tile of a wide schema: one wavefront
-constexpr int kMaxListDepth = 8;     // nested array/map levels
-constexpr int kMaxNest = 30;         // nested nullable-record / union / list levels (bit stacks)
-constexpr int kMaxUnionDepth = 8;    // nested N-variant unions (8-bit selector stack in a u64)
+// Nesting (walk.h stk_t / sel_t): a specialised kernel of a schema inside the SHALLOW bounds keeps 32-bit bit stacks and a 64-bit
+// selector stack; deeper schemas -- to the DEEP bounds -- and the interpreter take 64-bit / 128-bit ones (RH_DEEP).  The deep
+// bounds are beyond what apache-avro can parse into anything the reference decodes: serde_json stops at 128 JSON levels, a
+// nullable record costs four of them, an N-variant union of records five.
+constexpr int kShallowNest = 31, kShallowUnionDepth = 8;
+constexpr int kMaxListDepth = 62;    // nested array/map levels (one `remaining` counter per level and lane)
+constexpr int kMaxNest = 63;         // nested nullable-record / union / list levels (bit stacks)
+constexpr int kMaxUnionDepth = 16;   // nested N-variant unions (8-bit selector stack)
 // Null counts are added per workgroup with global atomics.  Atomics on ONE address from all over the chip serialise at
 // ~100 ns each (measured: a schema with two nullable columns, 10M records, 8 chunks = 4883 workgroups per address: the
 // emit kernel took 0.476 ms with them and 0.200 ms without, profiles/r03ag_nullcount_slots_ab.txt), so every
@@ -214,6 +219,7 @@ struct KParams {
   uint32_t* nullcount;       // [nnodes][k][null_slots]: a workgroup adds into slot (tile & (null_slots - 1)); rh_k_publish / the host sum the slots
   // specialised kernels only: k_size leaves every record's counters behind so k_emit does not re-walk
   uint32_t* lanecnt;         // [nblocks*TILE][ceil(K/2)] per-record counters, 16 bits each (saturated at 0xFFFF), record-major
+  uint32_t* lanecnt32;       // ranged kernels (tiles past the window): [nblocks*TILE][KL] the same counters, 32 bits each -- a record of such a tile is often larger than 16 bits count
   uint32_t* tileflag;        // [nblocks] TileFlag bits
   unsigned long long* prof;  // [32] phase cycle sums (RUHVRO_HIP_PROFILE=1 builds of the specialised kernels), else null
   // single-pass form (spec_body.h spec_fused): one launch sizes, scans (decoupled look-back over the tiles of a chunk) and emits

@@ -511,6 +511,8 @@ struct Builder {
   // make_decoder / make_nullable_decoder / make_union_decoder
   int build(const AvroType& t, bool nullable, bool null_first, Ctx cx) {
     if (cx.nest > kMaxNest) throw SchemaError("schema nesting too deep for the GPU decoder");
+    if (cx.nest > cs.max_nest) cs.max_nest = cx.nest;
+    if (cx.union_depth > cs.max_union_depth) cs.max_union_depth = cx.union_depth;
     switch (t.kind) {
       case AV_FIXED: case AV_DECIMAL: case AV_UUID: case AV_DURATION: {
         int id = new_node(NK_BIN);

@@ -105,6 +105,7 @@ struct CompiledSchema {
   bool wide = false;                // more than kWideCounters counters: tiles of one wavefront, wave counters (program.h F_WAVE_CTR)
   int ndom = 1;
   int list_depth = 0;
+  int max_nest = 0, max_union_depth = 0;   // deepest nullable-record / union / list nesting, deepest N-variant union nesting (program.h kShallow*)
   uint32_t min_record_bytes = 0;
   uint32_t max_row_bytes = 16;      // widest fixed-width value of one row (bounds the 32-bit in-buffer offsets of the specialised kernels)
   std::string encode_unsupported;   // non-empty: why rh_encode does not take this schema (no such schema today)

@@ -56,6 +56,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 
 constexpr int kBmWords = 64;      // LDS words per child-domain bitmap and tile (2048 rows before the global fallback)
+constexpr int kDirectRanges = 4;  // a tile past the window is staged in at most this many ranges; larger ones are walked from global memory in one piece (ranged_tile)
+constexpr int kScanSets = 4;      // item_scan: candidate starts per step = 64 x this (a span of 256 bytes)
 constexpr int kDenseCap = 128;    // item positions per wavefront and round of the item-dense list handling (dense_list)
 
 template <class S>
@@ -240,6 +242,128 @@ struct SpecSmem {
 // kDenseCap items; a wave with more alternates the two phases in rounds.  Only for tiles the size pass cleared (no
 // anomaly anywhere: RH_TRUST), so neither phase carries an error path; every other tile takes the per-record loop.
 // --------------------------------------------------------------------------
+// --------------------------------------------------------------------------
+// Wavefront-parallel item scan (round 6) for the list of ONE record larger than the window -- an array of millions of strings.
+// Finding the items of such a list is a chain of dependent reads (an item's start is the end of the one before it): one lane
+// alone pays a full LDS round trip and ~80 issue slots per item (~500 cycles; rounds 1-5: ~1400, from global memory), while 63
+// lanes watch.  Here every lane SPECULATES: lane j walks the item body as if an item began at byte cur + j (and cur + 64 + j, ...) and
+// notes where that item would end -- one step of the body for 256 candidate starts at once, reads that never leave the window's
+// guard (SlideSrc) and touch no counter but their own copy -- and the true chain is then followed through those 128 answers
+// with v_readlane, a few cycles per item, until it leaves the 256 bytes.  Block headers (one per block of items) are read in
+// between, wave-uniformly.  SIZE = false: the emit kernel's phase A (dense_list: positions -> tab, the bytes are trusted);
+// SIZE = true: the size walk of the ranged kernel (giant_list_size: counts and byte totals, every anomaly marks the lane `redo`).
+// --------------------------------------------------------------------------
+template <class S, int LID, int D, int DEPTH, bool SIZE, class Src, class Body>
+__device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane& L, Body&& body, int owner, uint32_t wbase, uint32_t lo, uint32_t limit,
+                                          uint32_t* tab, bool& inlist, uint32_t& top) {
+  uint32_t& rm = c.remaining(DEPTH);
+  // the list's state, wave-uniform (the owner lane's)
+  uint32_t cur_s = (uint32_t)__builtin_amdgcn_readlane((int)L.cur, owner);
+  uint32_t rm_s = (uint32_t)__builtin_amdgcn_readlane((int)rm, owner);
+  uint32_t idx_s = (uint32_t)__builtin_amdgcn_readlane((int)c.cnt[D], owner) - wbase;
+  bool in_s = ((__ballot(inlist) >> owner) & 1ull) != 0;
+  bool bad_s = false;
+  uint32_t acc[SCtx<S>::KL1];                               // SIZE: bytes the items met so far add to the body's string columns
+  static_for<0, S::KL>([&](auto ik) { acc[decltype(ik)::value] = 0; });
+  while (in_s && idx_s < limit && !bad_s) {
+    if (rm_s == 0) {                                        // at a block boundary: count, or the 0 terminator
+      uint32_t raw, n;
+      const bool ok = varint24(src.ld4(cur_s), SIZE ? (uint32_t)__builtin_amdgcn_readlane((int)L.end, owner) - cur_s : 4u, raw, n);      // (a cursor past the end: avail wraps, the end-of-record check of the fast walk catches it)
+      raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
+      n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+      if (SIZE && (!__builtin_amdgcn_readfirstlane((int)ok) || (raw & 1u))) { bad_s = true; break; }     // a long / negative count: the careful walk's
+      cur_s += n;
+      if ((raw >> 1) == 0) { in_s = false; break; }
+      rm_s = raw >> 1;
+    }
+    // the item body from kScanSets x 64 candidate starts
+    uint32_t nxt[kScanSets];
+    uint64_t redm[kScanSets];
+    SCtx<S> cz[kScanSets] = {c, c, c, c};
+    static_assert(kScanSets == 4, "cz is initialised for four sets");
+#pragma unroll
+    for (int h = 0; h < kScanSets; h++) {
+      static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; cz[h].cnt[k] = 0; });
+      Lane Lc;
+      Lc.live = true; Lc.pres = true; Lc.err = 0; Lc.edetail = 0; Lc.redo = false;
+      Lc.pstk = 0; Lc.lstk = 0; Lc.sstk = 0; Lc.la = 0;
+      Lc.cur = cur_s + (uint32_t)h * 64u + c.lane;
+      Lc.end = 0xFFFFFFFFu;
+      if constexpr (SIZE) body(IC<0>{}, cz[h], Lc);
+      else body(IC<0>{}, SkipCtx<SCtx<S>>(cz[h]), Lc);
+      nxt[h] = Lc.cur - cur_s;
+      redm[h] = SIZE ? __ballot(Lc.redo) : 0ull;
+    }
+    // follow the chain through the candidates
+    uint32_t pos = 0;
+    while (pos < (uint32_t)(64 * kScanSets) && rm_s > 0 && idx_s < limit) {
+      const int pl = (int)(pos & 63u), ps = (int)(pos >> 6);
+      if constexpr (!SIZE) {
+        if (c.lane == 0) tab[idx_s - lo] = cur_s + pos;
+      }
+      uint32_t nx = 0;
+#pragma unroll
+      for (int h = 0; h < kScanSets; h++) {
+        if (ps == h) {                                      // (wave-uniform)
+          if constexpr (SIZE) {
+            if ((redm[h] >> pl) & 1ull) bad_s = true;
+            static_for<0, S::KL>([&](auto ik) {
+              constexpr int k = decltype(ik)::value;
+              if constexpr (S::dense_body(LID, k)) acc[k] += (uint32_t)__builtin_amdgcn_readlane((int)cz[h].cnt[k], pl);
+            });
+          }
+          nx = (uint32_t)__builtin_amdgcn_readlane((int)nxt[h], pl);
+        }
+      }
+      if (bad_s) break;
+      pos = nx;
+      rm_s--; idx_s++;
+    }
+    if (bad_s) break;
+    cur_s += pos;
+    if constexpr (SIZE && Src::kSlide) {                    // keep the window under the cursor (no position is noted anywhere here)
+      const uint32_t delta = src.advance_to(cur_s, c.lane);
+      cur_s -= delta; L.cur -= delta; L.end -= delta;
+    }
+  }
+  // back to the owner lane
+  const bool mine = (int)c.lane == owner;
+  if (mine) {
+    L.cur = cur_s;
+    rm = rm_s;
+    c.cnt[D] = wbase + idx_s;
+    if constexpr (SIZE) {
+      static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; if constexpr (S::dense_body(LID, k)) c.cnt[k] += acc[k]; });
+      if (bad_s) L.redo = true;
+    }
+  }
+  inlist = mine ? in_s : false;
+  top = idx_s;
+}
+
+// The size walk's side of it: the list of a sliding record (one live lane), sized by item_scan in slices of 2^16 items with the
+// window moved along in between; an anomaly anywhere marks the lane `redo` (the careful walk then takes the record).  Leaves the
+// lane not live, so that the block loop behind it finds nothing to do.  Any other situation: not touched.
+template <class S, int LID, int D, int DEPTH, class Src, class Body>
+__device__ __forceinline__ void giant_list_size(const SCtx<S>& c, const Src& src, Lane& L, Body&& body) {
+  if constexpr (Src::kSlide) {
+    if (!src.sliding) return;
+    const uint64_t lv = __ballot(L.live);
+    if (lv == 0 || (lv & (lv - 1)) != 0) return;
+    const int owner = (int)__builtin_ctzll(lv);
+    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readlane((int)c.cnt[D], owner);
+    bool inlist = L.live;
+    uint32_t top = 0;
+    for (uint32_t lo = 0;; lo += 65536u) {
+      L.live = inlist;
+      src.refill(L, c.lane);
+      item_scan<S, LID, D, DEPTH, true>(c, src, L, body, owner, wbase, lo, lo + 65536u, (uint32_t*)nullptr, inlist, top);
+      if (!__any(inlist) || __any(L.redo)) break;
+    }
+    L.live = false; L.pres = false;
+  }
+}
+
 // LID: index of the list among the schema's dense lists; D: counter of its child row domain; DEPTH: its nesting depth (0).
 template <class S, int LID, int D, int DEPTH, class Src, class Body>
 __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lane& L, Body&& body) {
@@ -268,6 +392,14 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
     uint32_t top = 0;                                        // (SlideSrc) one past the last item this lane noted in this round
     if constexpr (Src::kSlide) { L.live = inlist; src.refill(L, c.lane); }      // (the table is empty here: positions may move)
     // phase A, one lane = one record: note where the items [lo, limit) of the wave start
+#ifndef RH_V_NOSCAN
+    if constexpr (Src::kSlide) {
+      if (src.sliding) {      // ONE record larger than the window: its one lane would find the items at one dependent read each
+        item_scan<S, LID, D, DEPTH, false>(c, src, L, body, first, wbase, lo, limit, tab, inlist, top);
+        goto scanned;
+      }
+    }
+#endif
     for (;;) {
       const bool need = inlist && rm == 0;                   // at a block boundary: count, or the 0 terminator
       uint32_t raw, n;
@@ -285,6 +417,7 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
       body(IC<0>{}, SkipCtx<SCtx<S>>(c), L);
       if (go) { rm -= 1; c.cnt[D] += 1; }
     }
+  scanned:
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // a wave's DS instructions execute in order: no barrier
     // phase B, one lane = one item
     uint32_t nr;
@@ -371,6 +504,66 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
   const uint32_t wcap = P.win_bytes & ~15u;
   uint32_t* const rng = s.gbx + SCtx<S>::KP;           // [NW] records of the range per wavefront (the single-pass form's exchange area: unused here)
+  // Records so large that the tile would take more than kDirectRanges ranges (a 200-column record is 1.5 KB: a dozen records
+  // per 17 KB window) leave most lanes of every range idle; such a tile is walked DIRECTLY instead: every lane on its own
+  // record, every read served from global memory (a SlideSrc with nothing staged) -- sixteen resident wavefronts per CU hide
+  // those round trips better than eleven busy lanes use a staged window (measured on the 200-column workload, 1M records:
+  // ranges 21.3 ms, the interpreter's global walk 9.8 ms, profiles/r06_e_*).  A record that is larger than the window by
+  // itself still gets its sliding range, in its place in the order of the records (the wave counters of a wide schema are
+  // scanned range by range): the tile is then [records in front of it, direct] [it, sliding] [records behind it, direct] ...
+  {
+    const uint64_t tb = P.offsets[g.rec0], te = P.offsets[g.rec0 + g.nrec];
+    const uint64_t o0m = tid < g.nrec ? P.offsets[g.rec0 + tid] : 0;
+    const bool bigme = tid < g.nrec && (o1 - (o0m & ~15ull)) > (uint64_t)wcap;
+    unsigned long long* const bigw = reinterpret_cast<unsigned long long*>(rng + 16);     // [NW] giant records per wavefront (rng[NW] meanwhile: their bytes / 16)
+    const uint64_t bm = __ballot(bigme);
+    if (lane == 0) { bigw[wave] = bm; rng[wave] = 0; }
+    __syncthreads();
+    if (bigme) atomicAdd(&rng[wave], (uint32_t)((o1 - o0m) >> 4));
+    __syncthreads();
+    uint64_t bigbytes = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) bigbytes += (uint64_t)rng[w] << 4;
+    __syncthreads();
+#ifdef RH_V_NODIRECT
+    if (false) {
+#else
+    if ((te - (tb & ~15ull)) - bigbytes > (uint64_t)kDirectRanges * wcap) {
+#endif
+      const uint64_t rb16 = tb & ~15ull;
+      uint32_t a = 0;
+      while (a < g.nrec) {
+        const uint64_t wm = bigw[a >> 6] >> (a & 63u);
+        if (wm & 1ull) {                               // record `a` by itself: a sliding range
+          const uint64_t r16 = P.offsets[g.rec0 + a] & ~15ull;
+          const uint64_t left = P.data_len - r16 + 15ull;
+          const uint32_t staged = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
+          if (wave == a / 64u) {
+            stage_wave(P.data + r16, P.data_len - r16, wa, staged, lane);
+            const SlideSrc src{wa, staged, wcap, P.data + r16, P.data_len - r16, true};
+            f(src, tid == a, r16);
+          }
+          __syncthreads();                             // (the window is one per workgroup)
+          a += 1;
+        } else {                                       // the records up to the next giant (or the end of the tile), directly
+          uint32_t b = g.nrec;
+          for (uint32_t w = a >> 6; w < (uint32_t)NW; w++) {
+            uint64_t m = bigw[w];
+            if (w == (a >> 6)) m &= ~0ull << (a & 63u);
+            if (m) { b = w * 64u + (uint32_t)__builtin_ctzll(m); break; }
+          }
+          if (b > g.nrec) b = g.nrec;
+          const bool inr = tid >= a && tid < b;
+          if (__any(inr)) {
+            const SlideSrc src{wa, 0u, wcap, P.data + rb16, P.data_len - rb16, false};
+            f(src, inr, rb16);
+          }
+          a = b;
+        }
+      }
+      return;
+    }
+  }
   uint32_t a = 0;
   while (a < g.nrec) {                                 // (workgroup-uniform)
     const uint64_t rb16 = P.offsets[g.rec0 + a] & ~15ull;
@@ -515,6 +708,29 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   RH_MARK(18);
 
   // per-record counters -> HBM (16 bits each, record-major: lanecnt_store) so that k_emit can skip its size walk
+  // (the ranged kernel hands them over with 32 bits each -- a record of a tile past the window is often larger than 16 bits
+  //  count, and a saturated tile costs the emit kernel a careful size walk: 80 % of a giant record's emit time before)
+  if constexpr (RANGED) {
+    static_for<0, S::KL>([&](auto ik) {
+      constexpr int k = decltype(ik)::value;
+      const uint32_t cv = c.cnt[k];
+      P.lanecnt32[((size_t)tile * T + tid) * S::KL + k] = cv;
+      const uint32_t v = wave_sum(cv);
+      if (lane == 0) s.wtot[wave * KP + k] = v;
+    });
+    if (lane == 0 && (careful || tflag)) {
+      atomicOr(&s.misc[2], (careful ? (uint32_t)TF_CAREFUL : 0u) | (tflag & (uint32_t)(TF_OVER_WINDOW | TF_SUBTILED)));
+      if (tflag & (uint32_t)TF_REWALK_ONE) atomicAdd(&s.misc[2], (uint32_t)TF_REWALK_ONE);
+    }
+    report_errors(P, s.misc, L, g, tid, tile);
+    if (tid == 0) P.tileflag[tile] = s.misc[2];
+    for (int k = tid; k < S::K; k += T) {
+      uint32_t tsum = 0;
+      for (int w = 0; w < NW; w++) tsum += s.wtot[w * KP + k];
+      P.blocksum[(size_t)k * P.nblocks + tile] = tsum;
+    }
+    return;
+  }
   bool sat = false;
   constexpr int NDW = (S::KL + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};
@@ -601,7 +817,8 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const bool careful = (tflag & 2u) != 0;
   constexpr int NDW = (S::KL + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};      // two 16-bit counters per dword, as k_size left them (unpacked after the scan)
-  if constexpr (S::KL > 0) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
+  if constexpr (S::KL > 0 && !RANGED) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
+  if constexpr (RANGED) static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = P.lanecnt32[((size_t)tile * T + tid) * S::KL + k]; });
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);
@@ -616,20 +833,14 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
 
   if (S::KL > 0) {
-    bool narrow = !rewalk;
-    if (rewalk) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
+    bool narrow = !rewalk && !RANGED;      // (the ranged kernel's counters are 32-bit: scanned one by one)
+    if (rewalk && !RANGED) {   // a counter saturated its 16-bit slot (a very long string / list): size this tile again
       static_for<0, S::KL>([&](auto ik) { c.cnt[decltype(ik)::value] = 0; });
       if constexpr (!RANGED) {
         lane_init_from(L, g, o0, o1, wb16, tid);
         spec_run_walk<S, false, true>(P, c, s.win, L, true, wb16);
-      } else {
-        ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src, bool inr, uint64_t rb16) {
-          Lane Lr;
-          lane_init_range(Lr, inr, o0, o1, rb16, wa);
-          S::template walk<false, true>(c, src, Lr);
-        });
       }
-    } else {
+    } else if constexpr (!RANGED) {
       // every counter of the wave below 1024: the inclusive scan of a PACKED dword cannot carry from its low half into
       // its high half (64 x 1023 < 2^16), so the wave scans two counters per dword -- half the DPP adds
       uint32_t allor = 0;

@@ -99,6 +99,9 @@ struct LdsSrc {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
     return __builtin_amdgcn_alignbyte(a[1], a[0], p & 3u);
   }
+  // 16 bytes at a 16-byte aligned position: one ds_read_b128
+  static constexpr bool kAligned16 = true;
+  __device__ __forceinline__ v4w ld16a(uint32_t p) const { return *reinterpret_cast<const v4w*>(w + p); }
   // >= 5 valid bytes (a 1-byte union branch + a varint of <= 4 bytes) from ONE ds_read2_b32
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(w + (p & ~3u));
@@ -171,6 +174,8 @@ struct LdsAbsSrc {
     const RH_LDS uint32_t* a = dw(p);
     d1 = a[j / 4 + 1]; d2 = a[j / 4 + 2];      // (ds_read2_b32 with immediate offsets off one address register)
   }
+  static constexpr bool kAligned16 = true;
+  __device__ __forceinline__ v4w ld16a(uint32_t p) const { return *reinterpret_cast<const RH_LDS v4w*>((uintptr_t)p); }      // one ds_read_b128
 };
 
 struct GlobalSrc {
@@ -205,6 +210,8 @@ struct GlobalSrc {
     r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32);
     return r;
   }
+  static constexpr bool kAligned16 = false;     // (global memory has no alignment cliff: ld16 is the read)
+  __device__ __forceinline__ v4w ld16a(uint32_t p) const { return ld16(p); }
 };
 
 // One WAVEFRONT stages `nbytes` (a multiple of 16) from global `g` (16-byte aligned) to LDS address `wa` by LDS-DMA: 1 KiB per
@@ -246,20 +253,25 @@ struct SlideSrc {
   // Move the window up to the cursor of the one live lane once it has used half of it (called at every list iteration, by
   // all 64 lanes: wave-uniform).  Every lane's cursor and end are rebased by the same distance; positions noted before the
   // call (dense_list's table) must have been used up.
-  template <class LaneT>
-  __device__ __forceinline__ void refill(LaneT& L, uint32_t lane) const {
-    if (!sliding) return;
-    const uint64_t lv = __ballot(L.live);
-    if (lv == 0 || (lv & (lv - 1)) != 0) return;                      // (one record per sliding range: one live lane)
-    const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)L.cur, (int)__builtin_ctzll(lv));
+  // the window up to position `cur` once half of it is used: returns the distance every position has to be rebased by (0: not moved)
+  __device__ __forceinline__ uint32_t advance_to(uint32_t cur, uint32_t lane) const {
+    if (!sliding) return 0;
     const uint32_t off = cur - wa;
-    if ((int32_t)off < (int32_t)(wcap / 2)) return;
+    if ((int32_t)off < (int32_t)(wcap / 2)) return 0;
     const uint32_t delta = off & ~15u;
     g += delta;
     glim -= delta;
     const uint64_t left = glim + 15ull;
     wlen = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
     stage_wave(g, glim, wa, wlen, lane);
+    return delta;
+  }
+  template <class LaneT>
+  __device__ __forceinline__ void refill(LaneT& L, uint32_t lane) const {
+    if (!sliding) return;
+    const uint64_t lv = __ballot(L.live);
+    if (lv == 0 || (lv & (lv - 1)) != 0) return;                      // (one record per sliding range: one live lane)
+    const uint32_t delta = advance_to((uint32_t)__builtin_amdgcn_readlane((int)L.cur, (int)__builtin_ctzll(lv)), lane);
     L.cur -= delta;
     L.end -= delta;
   }
@@ -289,6 +301,11 @@ struct SlideSrc {
   }
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
     if (in(p, 20)) return LdsAbsSrc().ld16(p);
+    uint32_t q; const GlobalSrc f = far(p, q); return f.ld16(q);
+  }
+  static constexpr bool kAligned16 = true;
+  __device__ __forceinline__ v4w ld16a(uint32_t p) const {      // (p 16-byte aligned -- window positions and wa are)
+    if (in(p, 16)) return LdsAbsSrc().ld16a(p);
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld16(q);
   }
   // (copy_bytes' batched pieces: aligned dwords around p -- the same bytes through whichever side holds all of them)
@@ -364,7 +381,7 @@ __device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE
 #define RH_COPY_FN __forceinline__
 #endif
 template <bool WIDE, class Src>
-__device__ RH_COPY_FN void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src& s, uint32_t sp, uint32_t len, bool anylong) {
+__device__ RH_COPY_FN void copy_bytes(void* base, typename BufOff<WIDE>::type d, const Src s, uint32_t sp, uint32_t len, bool anylong) {      // (the source BY VALUE: a reference into a real function -- RH_WIDE_SCHEMA -- would keep it in scratch memory)
   // A store instruction costs the CU's store path about (width x 64 lanes) / 18 cycles WHATEVER the number of active
   // lanes (tools/storecost.hip): what a column costs that path is its bytes rounded up to pieces, whatever the piece.
 #ifndef RH_V_NOBATCH
@@ -435,6 +452,23 @@ __device__ RH_COPY_FN void copy_bytes(void* base, typename BufOff<WIDE>::type d,
   // ... the others per lane: 16-byte pieces (two window reads in flight per round), 8..15 bytes as two overlapping
   // 8-byte stores, shorter ones by the set bits of their length
   if (len >= 16) {
+    if (Src::kAligned16 && __any(len >= 64u)) {
+      // Round 6: the pieces are cut where the SOURCE is 16-byte aligned -- one ds_read_b128 and one (unaligned) 16-byte store
+      // per piece, against five aligned dword reads and four v_alignbyte for a piece at any position: the first 16 bytes and
+      // the last 16 bytes of the string as before (overlapping the aligned pieces between them).  What a column of strings of
+      // a few hundred bytes costs the emit walk fell by a factor of four (the skewed workload, profiles/r06_f_*).
+      const v4w xh = s.ld16(sp), xt = s.ld16(sp + len - 16);
+      st_at<v4wu, WIDE>(base, d, xh);
+      uint32_t j = (16u - (sp & 15u)) & 15u;             // the first aligned source position behind sp
+      for (; j + 32 <= len; j += 32) {
+        const v4w x0 = s.ld16a(sp + j), x1 = s.ld16a(sp + j + 16);
+        st_at<v4wu, WIDE>(base, d + j, x0);
+        st_at<v4wu, WIDE>(base, d + j + 16, x1);
+      }
+      if (j + 16 <= len) st_at<v4wu, WIDE>(base, d + j, s.ld16a(sp + j));
+      st_at<v4wu, WIDE>(base, d + len - 16, xt);
+      return;
+    }
     uint32_t j = 0;
     for (; j + 32 <= len; j += 32) {
       const v4w x0 = s.ld16(sp + j), x1 = s.ld16(sp + j + 16);
@@ -496,10 +530,19 @@ __device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE
     typename BufOff<WIDE>::type d_j;
     if constexpr (WIDE) d_j = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)d >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)d, j);
     else d_j = (uint32_t)__builtin_amdgcn_readlane((int)d, j);
-    for (uint32_t off = rank * 16u; off < ln_j; off += nact * 16u) {
-      const uint32_t o = off + 16u <= ln_j ? off : ln_j - 16u;
-      const v4w x = s.ld16(sp_j + o);
-      st_at<v4wu, WIDE>(base, d_j + o, x);
+    if constexpr (Src::kAligned16) {
+      // pieces cut where the source is 16-byte aligned (one ds_read_b128 each); the string's first and last 16 bytes by the
+      // first two lanes, overlapping them
+      const uint32_t h = (16u - (sp_j & 15u)) & 15u;
+      if (rank == 0) st_at<v4wu, WIDE>(base, d_j, s.ld16(sp_j));
+      if (rank == (nact > 1 ? 1u : 0u)) st_at<v4wu, WIDE>(base, d_j + ln_j - 16u, s.ld16(sp_j + ln_j - 16u));
+      for (uint32_t off = h + rank * 16u; off + 16u <= ln_j; off += nact * 16u) st_at<v4wu, WIDE>(base, d_j + off, s.ld16a(sp_j + off));
+    } else {
+      for (uint32_t off = rank * 16u; off < ln_j; off += nact * 16u) {
+        const uint32_t o = off + 16u <= ln_j ? off : ln_j - 16u;
+        const v4w x = s.ld16(sp_j + o);
+        st_at<v4wu, WIDE>(base, d_j + o, x);
+      }
     }
   }
 }
@@ -521,6 +564,17 @@ __device__ __forceinline__ void copy_plain(D* d, const uint8_t* s, uint32_t len)
 // --------------------------------------------------------------------------
 // per-lane walker state
 // --------------------------------------------------------------------------
+// The bit stacks of a lane.  RH_DEEP (the interpreter always; a specialised kernel when its schema nests deeper than 31 nullable
+// records / unions / lists or 8 N-variant unions): 64-bit `live` / `pres` stacks and a 128-bit selector stack -- nesting to 63
+// and 16 levels.  apache-avro parses a schema with serde_json, whose recursion limit is 128 JSON levels (an array level costs
+// one, a nullable record four): deeper schemas than that cannot reach the reference's decoder either.
+#ifdef RH_DEEP
+typedef uint64_t stk_t;
+typedef unsigned __int128 sel_t;
+#else
+typedef uint32_t stk_t;
+typedef uint64_t sel_t;
+#endif
 struct Lane {
   uint32_t cur, end;   // byte cursor / record end, relative to the window base (cur <= end always)
   uint32_t err;        // ErrCode, 0 = ok
@@ -528,9 +582,9 @@ struct Lane {
   bool live, pres;     // an errored lane is dead: live = pres = false and its saved bits are cleared
   bool redo;           // fast walk only: this record left the fast wire forms and must be walked carefully
   uint64_t la;         // look-ahead: the window bytes at `cur`, left behind by the head in front (read_head LA bit 1)
-  uint32_t pstk;       // saved `pres` bits   (nullable record / union / list)
-  uint32_t lstk;       // saved `live` bits   (list)
-  uint64_t sstk;       // saved union selectors, 8 bits each
+  stk_t pstk;          // saved `pres` bits   (nullable record / union / list)
+  stk_t lstk;          // saved `live` bits   (list)
+  sel_t sstk;          // saved union selectors, 8 bits each
 };
 
 // First error of a record (the reference's `?` at fast_decode.rs:827): remember it and kill the lane so
@@ -559,8 +613,8 @@ __device__ __forceinline__ void reject(Lane& L, bool cond, uint32_t code, int64_
     L.redo = L.redo || cond;
     L.live = L.live && !cond;
     L.pres = L.pres && !cond;
-    L.pstk = cond ? 0u : L.pstk;
-    L.lstk = cond ? 0u : L.lstk;
+    L.pstk = cond ? (stk_t)0 : L.pstk;
+    L.lstk = cond ? (stk_t)0 : L.lstk;
   }
 }
 
@@ -1160,7 +1214,7 @@ __device__ __forceinline__ void h_bin(const Ctx& c, const Src& src, Lane& L, con
 template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_rec_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
-  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
+  L.pstk = (L.pstk << 1) | (stk_t)(L.pres ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
   const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, true, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);
@@ -1177,8 +1231,8 @@ __device__ __forceinline__ void h_rec_end(Lane& L) {
 template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
-  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
-  L.sstk = (L.sstk << 8) | 0xFFull;
+  L.pstk = (L.pstk << 1) | (stk_t)(L.pres ? 1u : 0u);
+  L.sstk = (L.sstk << 8) | (sel_t)0xFFull;
   const bool dec = act && L.pres;
   int64_t idx = 0;
   void* const pu1 = EMIT ? c.buf(op.buf1) : nullptr;           // requested ahead of the head: see h_string
@@ -1186,7 +1240,7 @@ __device__ __forceinline__ void h_union_begin(const Ctx& c, const Src& src, Lane
   const bool oor = got && (CAREFUL ? (idx < 0 || idx >= (int64_t)op.a) : (uint32_t)idx >= (uint32_t)op.a);
   RH_REJECT(L, oor, E_UNION, idx);
   uint32_t tidv = 0;
-  if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~0xFFull) | (uint64_t)idx; }
+  if (got && L.live) { tidv = (uint32_t)idx; L.sstk = (L.sstk & ~(sel_t)0xFFull) | (sel_t)(uint64_t)idx; }
   if (EMIT && act) st_global<int8_t, Ctx::kWide>(pu1, row_of(c, op.dom), (int8_t)tidv);
 }
 __device__ __forceinline__ void h_variant(Lane& L, const Op& op) {
@@ -1202,8 +1256,8 @@ __device__ __forceinline__ void h_union_end(Lane& L) {
 template <bool EMIT, bool CAREFUL, int LA = 0, class Src, class Ctx>
 __device__ __forceinline__ void h_list_begin(const Ctx& c, const Src& src, Lane& L, const Op& op) {
   const bool act = L.live;
-  L.pstk = (L.pstk << 1) | (L.pres ? 1u : 0u);
-  L.lstk = (L.lstk << 1) | (L.live ? 1u : 0u);
+  L.pstk = (L.pstk << 1) | (stk_t)(L.pres ? 1u : 0u);
+  L.lstk = (L.lstk << 1) | (stk_t)(L.live ? 1u : 0u);
   const bool dec = act && L.pres;
   int64_t dummy = 0;
   const bool isval = read_head<CAREFUL, RH_TRUST, (CAREFUL ? 0 : LA)>(src, L, dec, (op.flags & F_NULLABLE) != 0, (op.flags & F_NULL_FIRST) != 0, false, false, dummy);

@@ -39,7 +39,7 @@ def known_schemas() -> List[str]:
         import cases
         for c in cases.wire_cases() + cases.nesting_cases() + cases.dense_list_cases() + cases.enum_form_cases() + cases.wide_counter_cases():
             out.append(c[1])
-        for c in cases.wide_form_cases() + cases.giant_record_cases():
+        for c in cases.wide_form_cases() + cases.giant_record_cases() + cases.deep_nesting_cases():
             out.append(c[1])
         for c in cases.error_cases():
             out.append(c[1])

@@ -516,3 +516,53 @@ def giant_record_cases():
                      "post": "z" * (r % 20) if r != 65 else "Q" * 300_000})
     out.append(("giant_arrays", s, _enc(s, vals)))
     return out
+
+
+def deep_nesting_cases():
+    """Round 6: nesting beyond rounds 1-5's limits (8 list levels, 30 nullable-record / union / list levels, 8 N-variant unions):
+    12 nested arrays, 36 nested nullable records, 10 nested N-variant unions.  -> list of (name, schema_json, records)."""
+    out = []
+    # array<array<...<int>>> twelve deep
+    t = "int"
+    for _ in range(12):
+        t = {"type": "array", "items": t}
+    s = json.dumps({"type": "record", "name": "DL", "fields": [{"name": "a", "type": t}, {"name": "z", "type": "string"}]})
+
+    def nest(d, r):
+        if d == 0:
+            return r
+        return [nest(d - 1, r + j) for j in range((r + d) % 3)]
+    vals = [{"a": nest(12, r), "z": f"z{r}"} for r in range(90)]
+    out.append(("lists_12_deep", s, _enc(s, vals)))
+    # 36 nested nullable records, a string at every level
+    t = ["null", {"type": "record", "name": "N0", "fields": [{"name": "s", "type": "string"}]}]
+    for i in range(1, 36):
+        t = ["null", {"type": "record", "name": f"N{i}", "fields": [{"name": "s", "type": ["null", "string"]}, {"name": "c", "type": t}]}]
+    s = json.dumps({"type": "record", "name": "DR", "fields": [{"name": "r", "type": t}, {"name": "tail", "type": "int"}]})
+
+    def rec(level, depth, r):
+        if depth == 0:
+            return None
+        if level == 0:
+            return {"s": f"leaf{r}"}
+        return {"s": None if (r + level) % 3 == 0 else f"s{level}.{r}", "c": rec(level - 1, depth - 1, r)}
+    vals = [{"r": rec(35, (r * 7) % 38, r), "tail": r} for r in range(150)]
+    out.append(("nullable_records_36_deep", s, _enc(s, vals)))
+    # ten nested N-variant unions: ["null", "int", record{u: <next>}]
+    t = ["null", "int", "string"]
+    for i in range(10):
+        t = ["null", "int", {"type": "record", "name": f"U{i}", "fields": [{"name": "u", "type": t}, {"name": "k", "type": "long"}]}]
+    s = json.dumps({"type": "record", "name": "DU", "fields": [{"name": "u", "type": t}]})
+
+    def un(level, r):
+        if level == 0:
+            return [None, r, f"str{r}"][r % 3]
+        m = (r + level) % 4
+        if m == 0:
+            return None
+        if m == 1:
+            return r * level
+        return {"u": un(level - 1, r + 1), "k": r * 1_000_003 + level}
+    vals = [{"u": un(10, r)} for r in range(160)]
+    out.append(("unions_10_deep", s, _enc(s, vals)))
+    return out

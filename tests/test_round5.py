@@ -131,9 +131,11 @@ def test_num_chunks_equal_to_the_record_count(n):
 
 
 def test_one_giant_record_among_small_ones():
-    """One 60 MB record (an array of 2M strings) among 100,000 ordinary ones (fast_decode.rs:703-719 walks it item by item): its
-    tile does not fit the LDS window and is walked from global memory by one lane per record.  Correct on both kernel forms, and
-    bounded: seconds, not minutes (profiles/r05t_giant_record_lookahead.txt has the numbers and why)."""
+    """One 60 MB record (an array of 2M strings) among 100,000 ordinary ones (fast_decode.rs:703-719 walks it item by item).  Round
+    5: its tile was walked from global memory by one lane per record, 4.6-5.5 s on the specialised kernels, 50-145 x the CPU port.
+    Round 6: the record is a sliding range of its own (walk.h SlideSrc) whose items are found by the wavefront-parallel item scan
+    (spec_body.h item_scan) and emitted one lane per item: the specialised kernels stay within 10 x the CPU port of the same box
+    (VERDICT round 5, item 3); the interpreter has neither and keeps round 5's bound."""
     from avrogen.encoder import zigzag
     n, items = 100_000, 2_000_000
     data, offsets = fastgen.generate("full", n)
@@ -141,18 +143,29 @@ def test_one_giant_record_among_small_ones():
     body = bytearray(b"\x00\x00") + zigzag(items) + (zigzag(29) + b"x" * 29) * items + b"\x00" + b"\x00\x00\x00\x00" + \
         zigzag(1_750_000_000) + zigzag(1)
     recs[n // 2] = bytes(body)
-    exp = c_walker.decode_threaded(recs, SCHEMAS["full"], 8)
+    cpu = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        exp = c_walker.decode_threaded(recs, SCHEMAS["full"], 8)
+        cpu = min(cpu, time.perf_counter() - t0)
+    walls = {}
     for mode in ("generic", "specialized"):
         old = P.set_kernel_mode(mode)
         try:
-            t0 = time.perf_counter()
-            got = P.deserialize_array_threaded(recs, SCHEMAS["full"], 8)
-            wall = time.perf_counter() - t0
+            best = float("inf")
+            for _ in range(2):           # (the first call of a mode also takes its blocks from the allocator)
+                t0 = time.perf_counter()
+                got = P.deserialize_array_threaded(recs, SCHEMAS["full"], 8)
+                best = min(best, time.perf_counter() - t0)
         finally:
             P.set_kernel_mode(old)
         for g, e in zip(got, exp):
             assert_batches_identical(g, e)
-        assert wall < 30, f"{mode}: {wall:.1f} s"
+        walls[mode] = best
+    print(f"giant record: CPU port {cpu * 1e3:.0f} ms, specialised {walls['specialized'] * 1e3:.0f} ms "
+          f"({walls['specialized'] / cpu:.1f} x), generic {walls['generic'] * 1e3:.0f} ms ({walls['generic'] / cpu:.1f} x)")
+    assert walls["generic"] < 30, f"generic: {walls['generic']:.1f} s"
+    assert walls["specialized"] <= 10 * cpu, f"specialised {walls['specialized']:.2f} s vs CPU port {cpu:.3f} s"
 
 
 def test_allocation_failure_is_an_error_not_a_leak(monkeypatch):

@@ -253,3 +253,21 @@ def test_a_tile_past_the_window_without_the_ranged_pair_is_repeated_on_the_gener
         assert c1["ranged_retries"] > c0["ranged_retries"]
     finally:
         P.set_kernel_mode(old)
+
+
+# ---- nesting beyond rounds 1-5's limits ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", cases.deep_nesting_cases(), ids=lambda c: c[0])
+def test_oracles_agree_on_deep_nesting(case):
+    name, schema, recs = case
+    assert_batches_identical(c_walker.decode(recs, schema), py_walker.decode(recs, schema))
+    assert P.arrow_schema(schema) is not None            # the engine's front-end takes the schema (8 / 30 / 8 levels were the limits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases.deep_nesting_cases(), ids=lambda c: c[0])
+def test_deep_nesting(case, kernel):
+    """12 nested arrays, 36 nested nullable records, 10 nested N-variant unions: 64-bit bit stacks and a 128-bit selector stack
+    (walk.h RH_DEEP) in the interpreter and in the specialised kernels of such schemas."""
+    name, schema, recs = case
+    for k in (1, 3):
+        _check(recs, schema, k)
