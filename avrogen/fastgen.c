@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { CFG_FULL = 0, CFG_FLAT4 = 1, CFG_CFG3 = 2, CFG_REALISTIC = 3, CFG_REALISTIC_HEAVY = 4, CFG_SKEWED = 5, CFG_WIDE = 100 /* + columns */ };
+enum { CFG_FULL = 0, CFG_FLAT4 = 1, CFG_CFG3 = 2, CFG_REALISTIC = 3, CFG_REALISTIC_HEAVY = 4, CFG_SKEWED = 5, CFG_REALISTIC_NOGIANT = 6, CFG_WIDE = 100 /* + columns */ };
 
 static inline uint64_t mix(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -46,7 +46,7 @@ static inline uint8_t *put_str(uint8_t *p, const char *s, int n) {
 
 /* upper bound of one record's bytes per configuration (the part buffers keep that much room in front of every record) */
 static uint64_t max_rec(int cfg) {
-  if (cfg == CFG_REALISTIC || cfg == CFG_REALISTIC_HEAVY) return 9000ull * 30 + 9215 + 1024;
+  if (cfg == CFG_REALISTIC || cfg == CFG_REALISTIC_HEAVY || cfg == CFG_REALISTIC_NOGIANT) return 9000ull * 30 + 9215 + 1024;
   if (cfg == CFG_SKEWED) return 225ull * 384 + 4096;      /* every letter of gen_full x the largest scale (8 x 48) */
   if (cfg >= CFG_WIDE) return (uint64_t)(cfg - CFG_WIDE) * 19 + 12 * 48 + 256;
   return 512;
@@ -143,6 +143,7 @@ static uint8_t *gen_realistic_n(uint8_t *p, uint64_t seed, uint64_t row, uint64_
 }
 static uint8_t *gen_realistic(uint8_t *p, uint64_t seed, uint64_t row) { return gen_realistic_n(p, seed, row, 100); }
 static uint8_t *gen_realistic_heavy(uint8_t *p, uint64_t seed, uint64_t row) { return gen_realistic_n(p, seed, row, 10000); }
+static uint8_t *gen_realistic_nogiant(uint8_t *p, uint64_t seed, uint64_t row) { return gen_realistic_n(p, seed, row, 0); }
 
 /* synth.py skew_scale / gen_full_skewed */
 static int pick(const int (*t)[2], int n, uint64_t r) {
@@ -246,6 +247,7 @@ static gen_fn pick_gen(int cfg) {
     case CFG_FLAT4: return gen_flat4;
     case CFG_REALISTIC: return gen_realistic;
     case CFG_REALISTIC_HEAVY: return gen_realistic_heavy;
+    case CFG_REALISTIC_NOGIANT: return gen_realistic_nogiant;
     case CFG_SKEWED: return gen_skewed;
     default: return gen_cfg3;
   }

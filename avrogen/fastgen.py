@@ -9,7 +9,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "libfastgen.so")
-CFG = {"full": 0, "flat4": 1, "cfg3": 2, "full_realistic": 3, "full_realistic_heavy": 4, "full_skewed": 5,
+CFG = {"full": 0, "flat4": 1, "cfg3": 2, "full_realistic": 3, "full_realistic_heavy": 4, "full_skewed": 5, "full_realistic_nogiant": 6,
        "wide97": 100 + 97, "wide200": 100 + 200, "wide400": 100 + 400}
 _lib = None
 

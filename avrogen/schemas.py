@@ -169,7 +169,7 @@ SCHEMAS = {k: json.dumps(v) for k, v in {
     "t_nullable": T_NULLABLE, "t_logical": T_LOGICAL, "t_enum": T_ENUM, "t_nested": T_NESTED,
     "t_nullable_nested": T_NULLABLE_NESTED, "t_union": T_UNION, "t_array_str": T_ARRAY_STR,
     "t_array_int": T_ARRAY_INT, "t_map_str": T_MAP_STR,
-    "full_realistic": FULL_REALISTIC, "full_realistic_heavy": FULL_REALISTIC, "full_skewed": FULL,
+    "full_realistic": FULL_REALISTIC, "full_realistic_heavy": FULL_REALISTIC, "full_realistic_nogiant": FULL_REALISTIC, "full_skewed": FULL,
     **{f"wide{n}": wide_schema(n) for n in WIDE_COLS},
     "kat_user": KAT_USER, "kat_userdata": KAT_USERDATA, "kat_addresses": KAT_ADDRESSES, "kat_enum": KAT_ENUM,
 }.items()}

@@ -78,7 +78,7 @@ def gen_full(seed: int, row: int) -> dict:
 
 
 # ---- round 6: the full schema off its friendly value distribution --------------------
-BIG_ARRAY_PER_MILLION = {"full_realistic": 100, "full_realistic_heavy": 10_000}
+BIG_ARRAY_PER_MILLION = {"full_realistic": 100, "full_realistic_heavy": 10_000, "full_realistic_nogiant": 0}
 
 
 def _gen_realistic(seed: int, row: int, big_per_million: int) -> dict:
@@ -124,6 +124,10 @@ def gen_full_realistic(seed: int, row: int) -> dict:
 
 def gen_full_realistic_heavy(seed: int, row: int) -> dict:
     return _gen_realistic(seed, row, BIG_ARRAY_PER_MILLION["full_realistic_heavy"])
+
+
+def gen_full_realistic_nogiant(seed: int, row: int) -> dict:
+    return _gen_realistic(seed, row, 0)
 
 
 _SKEW_REC = ((512, 1), (768, 2), (896, 3), (960, 4), (992, 6), (1008, 8), (1016, 12), (1020, 16), (1022, 24), (1023, 32), (1024, 48))
@@ -234,7 +238,7 @@ GENERATORS: Dict[str, Callable[[int, int], dict]] = {
     "full": gen_full, "flat4": gen_flat4, "cfg3": gen_cfg3,
     "flat_primitives": gen_flat_primitives, "nullable_primitives": gen_nullable_primitives,
     "nested_struct": gen_nested_struct, "array_and_map": gen_array_and_map,
-    "full_realistic": gen_full_realistic, "full_realistic_heavy": gen_full_realistic_heavy, "full_skewed": gen_full_skewed,
+    "full_realistic": gen_full_realistic, "full_realistic_heavy": gen_full_realistic_heavy, "full_realistic_nogiant": gen_full_realistic_nogiant, "full_skewed": gen_full_skewed,
     "wide97": gen_wide(97), "wide200": gen_wide(200), "wide400": gen_wide(400),
 }
 

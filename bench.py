@@ -44,7 +44,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with these extra ob
                 (round 6, `workload_line`) the walks OFF the friendly value distribution, each with kernel times, the tile
                 statistics of rh_engine_counters and a parity_check against the oracle: `full_realistic_10m` (microsecond
                 timestamps, epoch-second ints, snowflake ids, 1 % notes of 8 KiB and more, arrays of > 8,191 items),
-                `full_skewed_10m` (record sizes log-normal in runs: a third of the tiles past the LDS window),
+                `full_realistic_nogiant_10m` (the same without those arrays), `full_skewed_10m` (record sizes log-normal in
+                runs: every tile past the 40 KB window),
                 `wide200_1m` (200 nullable string columns + 12 arrays: 224 scanned counters), and the GENERIC kernels --
                 what every new schema runs on while its specialised kernels compile -- on config 4 and config 3.
   end_to_end    (N=1 only) the same workload through the HOST entry points of the C ABI -- host records in, host
@@ -892,6 +893,7 @@ def other_configs(local_rank: int = 0, steps: int = 60):
     # round 6: the walks off the benchmark generator's distribution, wide schemas, and the generic kernels (`workload_line`)
     for name, (wl, n, kw) in {
         "full_realistic_10m": ("full_realistic", 10_000_000, {"parity_max": 2_000_000}),
+        "full_realistic_nogiant_10m": ("full_realistic_nogiant", 10_000_000, {"parity": False}),      # (the same without the > 8,191-item arrays: what one serial item chase per giant record costs the line above)
         "full_skewed_10m": ("full_skewed", 10_000_000, {"parity_max": 2_000_000}),
         "wide200_1m": ("wide200", 1_000_000, {}),
         "full10m_generic": ("full", 10_000_000, {"kernel": "generic", "reps": 8, "parity_max": 2_000_000}),

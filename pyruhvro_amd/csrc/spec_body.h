@@ -56,7 +56,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 
 constexpr int kBmWords = 64;      // LDS words per child-domain bitmap and tile (2048 rows before the global fallback)
-constexpr int kDirectRanges = 4;  // a tile past the window is staged in at most this many ranges; larger ones are walked from global memory in one piece (ranged_tile)
+constexpr int kDirectLanes = 24;  // a tile past the window whose ranges would hold fewer records than this on average is walked from global memory in one piece (ranged_tile)
 constexpr int kScanSets = 4;      // item_scan: candidate starts per step = 64 x this (a span of 256 bytes)
 constexpr int kDenseCap = 128;    // item positions per wavefront and round of the item-dense list handling (dense_list)
 
@@ -268,7 +268,7 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
   while (in_s && idx_s < limit && !bad_s) {
     if (rm_s == 0) {                                        // at a block boundary: count, or the 0 terminator
       uint32_t raw, n;
-      const bool ok = varint24(src.ld4(cur_s), SIZE ? (uint32_t)__builtin_amdgcn_readlane((int)L.end, owner) - cur_s : 4u, raw, n);      // (a cursor past the end: avail wraps, the end-of-record check of the fast walk catches it)
+      const bool ok = varint32(src.ld4(cur_s), SIZE ? (uint32_t)__builtin_amdgcn_readlane((int)L.end, owner) - cur_s : 4u, raw, n);      // (a cursor past the end: avail wraps, the end-of-record check of the fast walk catches it)
       raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw);
       n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
       if (SIZE && (!__builtin_amdgcn_readfirstlane((int)ok) || (raw & 1u))) { bad_s = true; break; }     // a long / negative count: the careful walk's
@@ -403,7 +403,7 @@ __device__ __forceinline__ void dense_list(const SCtx<S>& c, const Src& src, Lan
     for (;;) {
       const bool need = inlist && rm == 0;                   // at a block boundary: count, or the 0 terminator
       uint32_t raw, n;
-      (void)varint24(src.ld4(L.cur), 4u, raw, n);
+      (void)varint32(src.ld4(L.cur), 4u, raw, n);
       if (need) {
         L.cur += n;
         if ((raw >> 1) == 0) inlist = false;
@@ -504,8 +504,8 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
   const uint32_t wcap = P.win_bytes & ~15u;
   uint32_t* const rng = s.gbx + SCtx<S>::KP;           // [NW] records of the range per wavefront (the single-pass form's exchange area: unused here)
-  // Records so large that the tile would take more than kDirectRanges ranges (a 200-column record is 1.5 KB: a dozen records
-  // per 17 KB window) leave most lanes of every range idle; such a tile is walked DIRECTLY instead: every lane on its own
+  // Records so large that a range holds only a few of them (a 200-column record is 1.5 KB: a dozen records per 17 KB window)
+  // leave most lanes of every range idle; such a tile is walked DIRECTLY instead: every lane on its own
   // record, every read served from global memory (a SlideSrc with nothing staged) -- sixteen resident wavefronts per CU hide
   // those round trips better than eleven busy lanes use a staged window (measured on the 200-column workload, 1M records:
   // ranges 21.3 ms, the interpreter's global walk 9.8 ms, profiles/r06_e_*).  A record that is larger than the window by
@@ -525,11 +525,9 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
 #pragma unroll
     for (int w = 0; w < NW; w++) bigbytes += (uint64_t)rng[w] << 4;
     __syncthreads();
-#ifdef RH_V_NODIRECT
-    if (false) {
-#else
-    if ((te - (tb & ~15ull)) - bigbytes > (uint64_t)kDirectRanges * wcap) {
-#endif
+    // (fewer than kDirectLanes records per range on average -- bytes / window ranges for nrec records: the 200-column workload
+    //  has 11; the skewed workload's 2.5 ranges of ~100 records are better staged: 5.2 ms against 10.5 ms direct, profiles/r06_i_*)
+    if (((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {
       const uint64_t rb16 = tb & ~15ull;
       uint32_t a = 0;
       while (a < g.nrec) {

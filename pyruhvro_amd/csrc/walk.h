@@ -660,8 +660,8 @@ __device__ __forceinline__ uint32_t rd_varint_slow(const Src& src, uint32_t& cur
 // generator -- VERDICT round 5, item 2; the reference's read_zigzag_long, fast_decode.rs:854-869, costs the same for any length):
 //   int                       <= 5 bytes  (every i32; longer encodings of an int are legal and take the careful form)
 //   long                      <= 10 bytes (every i64, behind a branch byte too: timestamps in microseconds, snowflake ids)
-//   string / bytes length,
-//   array / map block count   <= 3 bytes  (below 2^20: 1 MiB, a million items)
+//   string / bytes length     <= 3 bytes  (below 2^20: 1 MiB)
+//   array / map block count   <= 4 bytes  (below 2^27 items)
 //   union / enum index        <= 2 bytes
 // Anything else -- padded encodings beyond these widths, an 11th byte, a varint running past the record -- is an anomaly.
 
@@ -1307,7 +1307,7 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
   const bool need = L.live && rm == 0;            // this lane is at a block boundary
   if (TRUST) {               // every block header of this tile took the one-read form below in the size pass, unclamped
     uint32_t raw, n;
-    (void)varint24(src.ld4(L.cur), 4u, raw, n);
+    (void)varint32(src.ld4(L.cur), 4u, raw, n);      // (a block count: the 4-byte form -- an array of two million items is met in production)
     if (need) {
       L.cur += n;
       if ((raw >> 1) == 0) L.live = false;
@@ -1324,7 +1324,7 @@ __device__ __forceinline__ bool h_list_next(const Ctx& c, const Src& src, Lane& 
   // lane fails here, so a garbage block count never starts a loop
   const int32_t left = (int32_t)(L.end - L.cur);
   const uint32_t lav = CAREFUL ? (uint32_t)left : (uint32_t)(left < 0 ? 0 : left);
-  const bool okv = varint24(x, lav, raw, n);
+  const bool okv = varint32(x, lav, raw, n);
   const bool fast = need && okv && (raw & 1u) == 0 && (op.buf2 > 0 || raw == 0);   // non-negative; zero-width items take the exact path
   const bool slow = need && !fast;
   if (fast) {

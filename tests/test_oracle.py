@@ -158,6 +158,8 @@ def test_walkers_agree_on_generated(name):
     b = c_walker.decode(recs, SCHEMAS[name])
     assert_batches_identical(a, b)
     exp = [synth.GENERATORS[name](11, i) for i in range(200)]
+    if name.startswith("full_realistic"):                              # (created_at is a timestamp-micros there: compare the raw integers)
+        a = a.set_column(a.schema.get_field_index("created_at"), "created_at", a.column("created_at").cast(pa.int64()))
     assert _norm(a.to_pylist()) == _norm(exp)                          # end-to-end known answer
 
 
@@ -206,6 +208,6 @@ def test_fastgen_matches_python_spec():
         d1, o1 = fastgen.generate(name, 3000, seed=5, start=17, nthreads=1)
         assert np.array_equal(d, d1) and np.array_equal(o, o1)
     # round 6: the workloads off the friendly distribution (long varints, 8 KiB strings, > 8,191-item arrays, record-size skew, wide records)
-    for name, n in (("full_realistic", 1500), ("full_realistic_heavy", 120), ("full_skewed", 1500), ("wide97", 200), ("wide200", 120), ("wide400", 60)):
+    for name, n in (("full_realistic", 1500), ("full_realistic_nogiant", 1500), ("full_realistic_heavy", 120), ("full_skewed", 1500), ("wide97", 200), ("wide200", 120), ("wide400", 60)):
         d, o = fastgen.generate(name, n, seed=5, start=17, nthreads=3)
         assert fastgen.split(d, o) == synth.records(name, n, seed=5, start=17), name

@@ -17,14 +17,17 @@ def test_generated_source_follows_the_schema_program():
     assert src.count("h_list_begin<EMIT, CAREFUL>") == 2 and src.count("for (;;)") == 2
     assert src.count("h_union_begin<EMIT, CAREFUL") == 1 and src.count("h_variant(") == 4
     assert src.count("h_rec_begin<EMIT, CAREFUL") == 2 and src.count("h_rec_end(L)") == 2
-    assert "static constexpr int K = 12, NDOM = 3" in src
+    assert "static constexpr int K = 12, KL = 12, NDOM = 3" in src
     # head fusion (walk.h read_head LA): the two record branch bytes open a 4-byte chain (2 | 4 << 2 = 18) that the record's
     # first string ends (1); the boolean in front of the union opens an 8-byte one (2 | 8 << 2 = 34) through the union index
     # (3) into the first head of each of its three non-null variants (1)
-    assert src.count("h_rec_begin<EMIT, CAREFUL, 18>") == 2 and src.count("h_fixed<EMIT, CAREFUL, 34>") == 1
+    # (round 6: a string's head is up to 3 bytes -- walk.h varint24 -- so the second record's branch byte + its nullable string
+    #  need 5 bytes: an 8-byte chain, 34; the first one's branch byte + plain string stay within 4, 18)
+    assert src.count("h_rec_begin<EMIT, CAREFUL, 18>") == 1 and src.count("h_rec_begin<EMIT, CAREFUL, 34>") == 1
+    assert src.count("h_fixed<EMIT, CAREFUL, 34>") == 1
     assert src.count("h_union_begin<EMIT, CAREFUL, 3>") == 1 and src.count("CAREFUL, 1>(c, src, L, op)") == 5
     flat = cabi.kernel_source(SCHEMAS["flat4"])
-    assert "static constexpr int K = 0, NDOM = 1" in flat and flat.count("h_fixed<EMIT, CAREFUL>") == 4
+    assert "static constexpr int K = 0, KL = 0, NDOM = 1" in flat and flat.count("h_fixed<EMIT, CAREFUL>") == 4
 
 
 def test_prebuild_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
@@ -33,17 +36,19 @@ def test_prebuild_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
     assert cabi.prebuild(schema) is False            # compiled now
     files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
     # every kernel is its own code object (compiled side by side by rh_kcompile helper processes, kernel_jobs.cpp):
-    # rh_spec_size / rh_spec_emit / rh_spec_fused and the Arrow -> Avro pair
-    assert len(files) == 5
+    # rh_spec_size / rh_spec_emit / rh_spec_fused, the ranged pair (tiles past the LDS window, round 6) and the Arrow -> Avro pair
+    assert len(files) == 7
     assert sorted(os.listdir(tmp_path)) == sorted(files)      # no lock / source / log files left behind
     blobs = [open(os.path.join(tmp_path, f), "rb").read() for f in files]
     assert all(b[:4] == b"\x7fELF" and b"gfx950" in b for b in blobs)
-    for entry in (b"rh_spec_size", b"rh_spec_emit", b"rh_spec_fused", b"rh_espec_size", b"rh_espec_emit"):
+    for entry in (b"rh_spec_fused", b"rh_espec_size", b"rh_espec_emit", b"rh_spec_size_r", b"rh_spec_emit_r"):
         assert sum(entry in b for b in blobs) == 1
+    for entry in (b"rh_spec_size", b"rh_spec_emit"):                 # (also a prefix of the ranged pair's names)
+        assert sum(entry in b for b in blobs) == 2
     assert cabi.prebuild(schema) is True             # nothing to compile
     assert cabi.prebuild(SCHEMAS["t_enum"] + "  ") is True     # another handle of the same schema: disk cache hit
     assert cabi.prebuild(SCHEMAS["t_union"] + " ") is False   # different schema -> different keys
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 10
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 14
     assert cabi.kernels_ready(schema) and cabi.kernels_ready(schema, encode=True)
 
 
@@ -51,7 +56,7 @@ def test_in_process_compile_when_the_helper_is_absent(tmp_path):
     """Without rh_kcompile next to the library the jobs compile on threads of the process (RUHVRO_HIP_KCOMPILE=0 forces it)."""
     code = ("import os, sys; from pyruhvro_amd import cabi; from avrogen.schemas import SCHEMAS\n"
             "assert cabi.prebuild(SCHEMAS['t_enum']) is False\n"
-            "assert len([f for f in os.listdir(os.environ['RUHVRO_HIP_KERNEL_CACHE']) if f.endswith('.hsaco')]) == 5\n")
+            "assert len([f for f in os.listdir(os.environ['RUHVRO_HIP_KERNEL_CACHE']) if f.endswith('.hsaco')]) == 7\n")
     env = dict(os.environ, RUHVRO_HIP_KERNEL_CACHE=str(tmp_path), RUHVRO_HIP_KCOMPILE="0")
     subprocess.check_call([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
