@@ -58,6 +58,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kBmWords = 64;      // LDS words per child-domain bitmap and tile (2048 rows before the global fallback)
 constexpr int kDirectLanes = 24;  // a tile past the window whose ranges would hold fewer records than this on average is walked from global memory in one piece (ranged_tile)
 constexpr int kScanSets = 4;      // item_scan: candidate starts per step = 64 x this (a span of 256 bytes)
+constexpr uint32_t kRangeSlack = 64; // bytes staged behind a range's last record (ranged_tile)
 constexpr int kDenseCap = 128;    // item positions per wavefront and round of the item-dense list handling (dense_list)
 
 template <class S>
@@ -322,7 +323,7 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
     if (bad_s) break;
     cur_s += pos;
     if constexpr (SIZE && Src::kSlide) {                    // keep the window under the cursor (no position is noted anywhere here)
-      const uint32_t delta = src.advance_to(cur_s, c.lane);
+      const uint32_t delta = src.advance_to(cur_s, c.lane, owner);
       cur_s -= delta; L.cur -= delta; L.end -= delta;
     }
   }
@@ -503,6 +504,12 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
   const uint32_t wcap = P.win_bytes & ~15u;
+  // A range is staged WITH the kRangeSlack bytes behind its last record (the next record's first bytes, or zeros at the end of
+  // the payload): the walk's window reads reach up to 20 bytes past a cursor, and a read that is not completely inside the staged
+  // bytes is served from global memory (SlideSrc) -- for the last fields of a range's last record that was a global load behind
+  // every store the wavefront had in flight (vmcnt counts in order on this part): the friendly workload forced through the
+  // ranged pair took the emit kernel 5.2 ms where it takes the kernel of the tiles that fit 0.73 ms (profiles/r06_k_*).
+  const uint32_t wfit = wcap > 4096u ? wcap - kRangeSlack : wcap;
   uint32_t* const rng = s.gbx + SCtx<S>::KP;           // [NW] records of the range per wavefront (the single-pass form's exchange area: unused here)
   // Records so large that a range holds only a few of them (a 200-column record is 1.5 KB: a dozen records per 17 KB window)
   // leave most lanes of every range idle; such a tile is walked DIRECTLY instead: every lane on its own
@@ -514,7 +521,7 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   {
     const uint64_t tb = P.offsets[g.rec0], te = P.offsets[g.rec0 + g.nrec];
     const uint64_t o0m = tid < g.nrec ? P.offsets[g.rec0 + tid] : 0;
-    const bool bigme = tid < g.nrec && (o1 - (o0m & ~15ull)) > (uint64_t)wcap;
+    const bool bigme = tid < g.nrec && (o1 - (o0m & ~15ull)) > (uint64_t)wfit;
     unsigned long long* const bigw = reinterpret_cast<unsigned long long*>(rng + 16);     // [NW] giant records per wavefront (rng[NW] meanwhile: their bytes / 16)
     const uint64_t bm = __ballot(bigme);
     if (lane == 0) { bigw[wave] = bm; rng[wave] = 0; }
@@ -527,7 +534,7 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
     __syncthreads();
     // (fewer than kDirectLanes records per range on average -- bytes / window ranges for nrec records: the 200-column workload
     //  has 11; the skewed workload's 2.5 ranges of ~100 records are better staged: 5.2 ms against 10.5 ms direct, profiles/r06_i_*)
-    if (((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {
+    if (SCtx<S>::kWaveCtr && ((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {      // (wide schemas: short strings; a narrow schema's large records are large STRINGS, better copied out of a staged range -- skewed workload 5.2 ms against 10.7 ms)
       const uint64_t rb16 = tb & ~15ull;
       uint32_t a = 0;
       while (a < g.nrec) {
@@ -565,7 +572,7 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   uint32_t a = 0;
   while (a < g.nrec) {                                 // (workgroup-uniform)
     const uint64_t rb16 = P.offsets[g.rec0 + a] & ~15ull;
-    const bool fitme = tid >= a && tid < g.nrec && (o1 - rb16) <= (uint64_t)wcap;      // offsets are monotonic: a prefix of [a, nrec)
+    const bool fitme = tid >= a && tid < g.nrec && (o1 - rb16) <= (uint64_t)wfit;      // offsets are monotonic: a prefix of [a, nrec)
     const uint32_t wc = (uint32_t)__popcll(__ballot(fitme));
     if (lane == 0) rng[wave] = wc;
     __syncthreads();
@@ -576,7 +583,8 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
     const uint32_t b = single ? a + 1u : a + cnt;
     uint32_t staged;
     if (!single) {
-      const uint64_t re = P.offsets[g.rec0 + b];
+      uint64_t re = P.offsets[g.rec0 + b] + (wfit < wcap ? (uint64_t)kRangeSlack - 16u : 0u);
+      if (re > P.data_len + 16u) re = P.data_len + 16u;       // (stage_window zero-fills one vector past the payload)
       stage_window<T>(P, s.win, rb16, re, tid);
       staged = (uint32_t)((re - rb16 + 15) & ~15ull);
     } else {
@@ -696,7 +704,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
         static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
         lane_init_range(Lr, inr, o0, o1, rb16, wa);
         const SlideSrc src2 = src0;        // the record again from its first byte: a window that has moved is staged anew
-        if (src0.sliding && src.g != src0.g) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
+        if (src0.sliding && __any(src.g != src0.g)) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
         S::template walk<false, true>(c, src2, Lr);
       }
       commit_wave_counters();
@@ -709,11 +717,10 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   // (the ranged kernel hands them over with 32 bits each -- a record of a tile past the window is often larger than 16 bits
   //  count, and a saturated tile costs the emit kernel a careful size walk: 80 % of a giant record's emit time before)
   if constexpr (RANGED) {
+    if constexpr (S::KL > 0) lanecnt_store<SCtx<S>::KL1>(P.lanecnt32 + ((size_t)tile * T + tid) * S::KL, c.cnt);      // (16-byte pieces)
     static_for<0, S::KL>([&](auto ik) {
       constexpr int k = decltype(ik)::value;
-      const uint32_t cv = c.cnt[k];
-      P.lanecnt32[((size_t)tile * T + tid) * S::KL + k] = cv;
-      const uint32_t v = wave_sum(cv);
+      const uint32_t v = wave_sum(c.cnt[k]);
       if (lane == 0) s.wtot[wave * KP + k] = v;
     });
     if (lane == 0 && (careful || tflag)) {
@@ -816,7 +823,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   constexpr int NDW = (S::KL + 1) / 2;
   uint32_t packed[NDW > 0 ? NDW : 1] = {};      // two 16-bit counters per dword, as k_size left them (unpacked after the scan)
   if constexpr (S::KL > 0 && !RANGED) lanecnt_load<NDW>(P.lanecnt + ((size_t)tile * T + tid) * NDW, packed);
-  if constexpr (RANGED) static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; c.cnt[k] = P.lanecnt32[((size_t)tile * T + tid) * S::KL + k]; });
+  if constexpr (RANGED && S::KL > 0) lanecnt_load<SCtx<S>::KL1>(P.lanecnt32 + ((size_t)tile * T + tid) * S::KL, c.cnt);
   const uint64_t wb16 = wb & ~15ull;
   const bool fits = (we - wb16) <= (uint64_t)P.win_bytes;
   RH_MARK(0);

@@ -233,6 +233,26 @@ __device__ __forceinline__ void stage_wave(const uint8_t* g, uint64_t gvalid, ui
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// The same by WHATEVER lanes of the wavefront are active.  SlideSrc::refill runs at the head of every list iteration of a
+// record larger than the window, and the compiler is free to execute such a loop with only the lanes that still have items
+// enabled (observed: EXEC = the one live lane inside the block loops of an array of arrays, profiles/r06_o_*): the LDS-DMA form
+// above then stages one 16-byte piece per KiB and leaves the rest of the window stale.  All lanes active: the DMA form; else
+// the active lanes deal the pieces among themselves (through registers: an LDS-DMA lands at M0 + lane id x 16).
+__device__ __forceinline__ void stage_wave_any(const uint8_t* g, uint64_t gvalid, uint32_t wa, uint32_t nbytes, uint32_t lane) {
+  const uint64_t ex = __ballot(true);
+  if (ex == ~0ull) { stage_wave(g, gvalid, wa, nbytes, lane); return; }
+  const uint32_t cnt = (uint32_t)__popcll(ex);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u));
+  const uint32_t nfull = (uint64_t)nbytes <= gvalid ? nbytes : (uint32_t)(gvalid & ~15ull);
+  for (uint32_t o = rank * 16u; o < nfull; o += cnt * 16u) {
+    const v4w x = *reinterpret_cast<const v4w*>(g + o);
+    *reinterpret_cast<RH_LDS v4w*>((uintptr_t)(wa + o)) = x;
+  }
+  for (uint32_t i = nfull + rank; i < nbytes; i += cnt)
+    *reinterpret_cast<RH_LDS uint8_t*>((uintptr_t)(wa + i)) = (uint64_t)i < gvalid ? g[i] : (uint8_t)0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // Round 6: the source of every tile that does not fit the LDS window in one piece.  Positions are LDS byte addresses like
 // LdsAbsSrc's (window byte 0 = `wa`), but only the first `wlen` bytes behind `wa` are staged: a read that is not completely
 // inside them is served from global memory at the same offset from `g` (per lane; positions in front of the window -- a lane
@@ -250,20 +270,29 @@ struct SlideSrc {
   mutable uint64_t glim;  // readable bytes behind g
   bool sliding;           // a single record larger than the window: refill() moves the window
   __device__ __forceinline__ bool in(uint32_t p, uint32_t need) const { return p - wa + need <= wlen; }      // (unsigned: false in front of the window)
-  // Move the window up to the cursor of the one live lane once it has used half of it (called at every list iteration, by
-  // all 64 lanes: wave-uniform).  Every lane's cursor and end are rebased by the same distance; positions noted before the
-  // call (dense_list's table) must have been used up.
-  // the window up to position `cur` once half of it is used: returns the distance every position has to be rebased by (0: not moved)
-  __device__ __forceinline__ uint32_t advance_to(uint32_t cur, uint32_t lane) const {
+  // Move the window up to the cursor of the one live lane (`owner`) once it has used half of it (called at every list
+  // iteration / dense round).  Returns the distance every position has to be rebased by (0: not moved); positions noted before
+  // the call (dense_list's table) must have been used up.  g / glim / wlen are per-lane copies of wave-level state, and a lane
+  // that was masked off during an earlier call (see stage_wave_any) kept an older base: the OWNER's copy is the authoritative
+  // one -- it takes part in every call, since a call without it finds no live lane -- and every call starts from it.
+  __device__ __forceinline__ void sync(int owner) const {
+    const uint64_t ga = (uint64_t)reinterpret_cast<uintptr_t>(g);
+    const uint64_t go = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ga >> 32), owner) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ga, owner);
+    g = reinterpret_cast<const uint8_t*>((uintptr_t)go);
+    glim = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(glim >> 32), owner) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)glim, owner);
+    wlen = (uint32_t)__builtin_amdgcn_readlane((int)wlen, owner);
+  }
+  __device__ __forceinline__ uint32_t advance_to(uint32_t cur, uint32_t lane, int owner) const {
     if (!sliding) return 0;
     const uint32_t off = cur - wa;
     if ((int32_t)off < (int32_t)(wcap / 2)) return 0;
+    sync(owner);
     const uint32_t delta = off & ~15u;
     g += delta;
     glim -= delta;
     const uint64_t left = glim + 15ull;
     wlen = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
-    stage_wave(g, glim, wa, wlen, lane);
+    stage_wave_any(g, glim, wa, wlen, lane);
     return delta;
   }
   template <class LaneT>
@@ -271,7 +300,9 @@ struct SlideSrc {
     if (!sliding) return;
     const uint64_t lv = __ballot(L.live);
     if (lv == 0 || (lv & (lv - 1)) != 0) return;                      // (one record per sliding range: one live lane)
-    const uint32_t delta = advance_to((uint32_t)__builtin_amdgcn_readlane((int)L.cur, (int)__builtin_ctzll(lv)), lane);
+    const int owner = (int)__builtin_ctzll(lv);
+    sync(owner);                                                      // (lanes that sat out earlier calls catch up: dense_list's item lanes, copy_bytes_coop)
+    const uint32_t delta = advance_to((uint32_t)__builtin_amdgcn_readlane((int)L.cur, owner), lane, owner);
     L.cur -= delta;
     L.end -= delta;
   }
@@ -525,6 +556,7 @@ __device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE
   while (big) {
     const int j = (int)__builtin_ctzll(big);
     big &= big - 1;
+    if constexpr (Src::kSlide) { if (s.sliding) s.sync(j); }      // (the string's own lane holds the window state: SlideSrc::advance_to)
     const uint32_t sp_j = (uint32_t)__builtin_amdgcn_readlane((int)sp, j);
     const uint32_t ln_j = (uint32_t)__builtin_amdgcn_readlane((int)len, j);
     typename BufOff<WIDE>::type d_j;
@@ -1088,7 +1120,11 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
       }
     }
     if constexpr (Src::kSlide) {
-      if (big) copy_bytes_coop<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len, big, c.lane, 64u);
+      if (big) {      // by the lanes that are active here: all 64, unless the compiler runs an enclosing block loop with its live lanes only
+        const uint64_t ex = __ballot(true);
+        copy_bytes_coop<Ctx::kWide>(pb2, (typename BufOff<Ctx::kWide>::type)gb + o, src, spos, len, big,
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)), (uint32_t)__popcll(ex));
+      }
     }
   }
   if (!wctr) c.counter(op.a) = o + len;   // len == 0 for every lane that does not carry a value
