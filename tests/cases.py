@@ -515,6 +515,32 @@ def giant_record_cases():
                      "nest": [[j, j + 1, j + 2][: j % 4] for j in range(n if n < 100 else 5_000)],
                      "post": "z" * (r % 20) if r != 65 else "Q" * 300_000})
     out.append(("giant_arrays", s, _enc(s, vals)))
+    # Nested (non item-dense) lists in FRONT of dense ones inside a record larger than the window, long strings inside the nested
+    # lists and behind them: the compiler may run a block loop with its live lanes only, so a window refill, a long string's
+    # cooperative copy and the dense list behind the loop all meet lanes that sat out earlier refills (profiles/r06_o_*).
+    s = json.dumps({"type": "record", "name": "GN", "fields": [
+        {"name": "id", "type": "int"},
+        {"name": "words", "type": {"type": "array", "items": {"type": "array", "items": "string"}}},
+        {"name": "mid", "type": "string"},
+        {"name": "tags", "type": {"type": "array", "items": "string"}},
+        {"name": "groups", "type": {"type": "map", "values": {"type": "array", "items": ["null", "long"]}}},
+        {"name": "opt", "type": ["null", {"type": "array", "items": "string"}]},
+        {"name": "tail", "type": ["null", "string"]}]})
+    vals = []
+    for r in range(300):
+        giant = r in (7, 130, 131, 299)
+        n = [0, 1, 3, 2][r % 4]
+        if giant:
+            n = [6_000, 20_000, 3_000, 9_000][(7, 130, 131, 299).index(r)]
+        vals.append({"id": r - 150,
+                     "words": [[("w%d-%d-%d" % (r, j, i)) * (1 + (40 if (j + i) % 97 == 0 and giant else (j + i) % 3)) for i in range(j % 4)]
+                               for j in range(n)],
+                     "mid": "M" * (70_000 if r == 130 else r % 9),
+                     "tags": [f"t{j}" * (1 + j % 2) for j in range(n // 2)],
+                     "groups": [(f"g{j}", [None if (i + j) % 4 == 0 else (j << 20) - i for i in range(j % 5)]) for j in range(min(n, 1_500))],
+                     "opt": None if r % 5 == 0 else [chr(48 + j % 70) * (300 if j % 501 == 0 and giant else j % 6) for j in range(n // 4)],
+                     "tail": None if r % 2 else "x" * (r % 300)})
+    out.append(("giant_nested", s, _enc(s, vals)))
     return out
 
 
