@@ -595,8 +595,17 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
     __syncthreads();
     const bool inr = tid >= a && tid < b;
     if (__any(inr)) {
-      const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, single};
-      f(src, inr, rb16);
+      // a range staged whole is read like the window of a tile that fits (RangeSrc: no in-window test behind every head); wide
+      // schemas keep the one SlideSrc walk (their kernels' size and compile time: a second instance of every walk)
+      if constexpr (SCtx<S>::kWaveCtr) {
+        const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, single};
+        f(src, inr, rb16);
+      } else if (single) {
+        const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, true};
+        f(src, inr, rb16);
+      } else {
+        f(RangeSrc{}, inr, rb16);
+      }
     }
     __syncthreads();                                   // the window is free for the next range
     a = b;
@@ -691,10 +700,11 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     tflag = (uint32_t)(TF_OVER_WINDOW | TF_SUBTILED);
     lane_init_range(L, false, 0, 0, 0, 0);
     const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
-    ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src0, bool inr, uint64_t rb16) {
+    ranged_tile<S>(P, s, g, o1, tid, [&](auto src0, bool inr, uint64_t rb16) {      // (SlideSrc, or RangeSrc for a range staged whole)
+      using SrcT = decltype(src0);
       Lane Lr;
       lane_init_range(Lr, inr, o0, o1, rb16, wa);
-      const SlideSrc src = src0;           // (a sliding range moves ITS copy of the window along: refill)
+      const SrcT src = src0;               // (a sliding range moves ITS copy of the window along: refill)
       S::template walk<false, false>(c, src, Lr);
       Lr.redo = Lr.redo || Lr.cur > Lr.end;
       if (__any(Lr.redo)) {
@@ -703,8 +713,10 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
         static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; if (inr) c.cnt[k] = 0; });
         static_for<0, (S::DEPTH > 0 ? S::DEPTH : 1)>([&](auto id) { c.rem[decltype(id)::value] = 0; });
         lane_init_range(Lr, inr, o0, o1, rb16, wa);
-        const SlideSrc src2 = src0;        // the record again from its first byte: a window that has moved is staged anew
-        if (src0.sliding && __any(src.g != src0.g)) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
+        const SrcT src2 = src0;            // the record again from its first byte: a window that has moved is staged anew
+        if constexpr (SrcT::kMoves) {
+          if (src0.sliding && __any(src.g != src0.g)) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
+        }
         S::template walk<false, true>(c, src2, Lr);
       }
       commit_wave_counters();
@@ -925,7 +937,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   } else {
     // the tile in ranges, as the size pass walked it (ranged_tile: same offsets, same window, same ranges)
     lane_init_range(L, false, 0, 0, 0, 0);
-    ranged_tile<S>(P, s, g, o1, tid, [&](const SlideSrc& src, bool inr, uint64_t rb16) {
+    ranged_tile<S>(P, s, g, o1, tid, [&](const auto& src, bool inr, uint64_t rb16) {
       Lane Lr;
       lane_init_range(Lr, inr, o0, o1, rb16, wa);
       if (careful) {

@@ -263,6 +263,7 @@ __device__ __forceinline__ void stage_wave_any(const uint8_t* g, uint64_t gvalid
 // was the whole cost of a giant record (profiles/r05t_*: ~1400 cycles per item).
 struct SlideSrc {
   static constexpr bool kSlide = true;
+  static constexpr bool kMoves = true;      // (its window can move: refill)
   uint32_t wa;            // LDS address of window byte 0 (wave-uniform, 16-byte aligned)
   mutable uint32_t wlen;  // staged bytes behind wa (wave-uniform; zero-filled past the end of the payload)
   uint32_t wcap;          // bytes the window can hold (a multiple of 16)
@@ -350,6 +351,21 @@ struct SlideSrc {
     const uint64_t x = f.ld8(q);
     d1 = (uint32_t)x; d2 = (uint32_t)(x >> 32);
   }
+};
+
+// A RANGE of records that is staged whole, slack included (spec_body.h ranged_tile): no read of a record of the range leaves the
+// staged bytes, so the walk reads the window like the kernels of the tiles that fit -- LdsAbsSrc's unchecked aligned reads, no
+// in-window test and no global-memory arm behind every head -- while the handlers keep their range-aware forms (kSlide: bitmap
+// words accumulated over the ranges, dense lists that count their items as they meet them).  A lane of the fast walk that
+// lost its record reads LDS wherever its cursor points (out of range: zero), as it does in those kernels.
+struct RangeSrc : LdsAbsSrc {
+  static constexpr bool kSlide = true;
+  static constexpr bool kMoves = false;
+  static constexpr bool sliding = false;
+  template <class LaneT>
+  __device__ __forceinline__ void refill(LaneT&, uint32_t) const {}
+  __device__ __forceinline__ uint32_t advance_to(uint32_t, uint32_t, int) const { return 0; }
+  __device__ __forceinline__ void sync(int) const {}
 };
 
 // Arrow buffers live in HBM: typed global-address-space accessors keep the compiler from emitting
