@@ -518,7 +518,7 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   // ranges 21.3 ms, the interpreter's global walk 9.8 ms, profiles/r06_e_*).  A record that is larger than the window by
   // itself still gets its sliding range, in its place in the order of the records (the wave counters of a wide schema are
   // scanned range by range): the tile is then [records in front of it, direct] [it, sliding] [records behind it, direct] ...
-  {
+  if constexpr (SCtx<S>::kWaveCtr) {
     const uint64_t tb = P.offsets[g.rec0], te = P.offsets[g.rec0 + g.nrec];
     const uint64_t o0m = tid < g.nrec ? P.offsets[g.rec0 + tid] : 0;
     const bool bigme = tid < g.nrec && (o1 - (o0m & ~15ull)) > (uint64_t)wfit;
@@ -534,7 +534,7 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
     __syncthreads();
     // (fewer than kDirectLanes records per range on average -- bytes / window ranges for nrec records: the 200-column workload
     //  has 11; the skewed workload's 2.5 ranges of ~100 records are better staged: 5.2 ms against 10.5 ms direct, profiles/r06_i_*)
-    if (SCtx<S>::kWaveCtr && ((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {      // (wide schemas: short strings; a narrow schema's large records are large STRINGS, better copied out of a staged range -- skewed workload 5.2 ms against 10.7 ms)
+    if (((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {      // (wide schemas: short strings; a narrow schema's large records are large STRINGS, better copied out of a staged range -- skewed workload 5.2 ms against 10.7 ms)
       const uint64_t rb16 = tb & ~15ull;
       uint32_t a = 0;
       while (a < g.nrec) {
@@ -569,21 +569,33 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
       return;
     }
   }
+  // (a range's bounds come from the record bounds the lanes hold in registers, through LDS -- not from offsets[] again: two
+  //  dependent global loads per range in front of its staging)
+  unsigned long long* const omax = reinterpret_cast<unsigned long long*>(rng + 32);      // [NW] end of the wavefront's last record that fits
+  unsigned long long* const o1a = reinterpret_cast<unsigned long long*>(rng + 48);       // end of record `a`
+  const uint32_t o1lo = (uint32_t)o1, o1hi = (uint32_t)(o1 >> 32);
+  auto o1_of = [&](int l) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)o1hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)o1lo, l); };
   uint32_t a = 0;
+  uint64_t ra = P.offsets[g.rec0];                     // first byte of record `a`
   while (a < g.nrec) {                                 // (workgroup-uniform)
-    const uint64_t rb16 = P.offsets[g.rec0 + a] & ~15ull;
+    const uint64_t rb16 = ra & ~15ull;
     const bool fitme = tid >= a && tid < g.nrec && (o1 - rb16) <= (uint64_t)wfit;      // offsets are monotonic: a prefix of [a, nrec)
-    const uint32_t wc = (uint32_t)__popcll(__ballot(fitme));
+    const uint64_t fm = __ballot(fitme);
+    const uint32_t wc = (uint32_t)__popcll(fm);
+    if (wc) { const uint64_t e = o1_of(63 - (int)__builtin_clzll(fm)); if (lane == 0) omax[wave] = e; }
+    if (wave == a / 64u) { const uint64_t e = o1_of((int)(a & 63u)); if (lane == 0) *o1a = e; }
     if (lane == 0) rng[wave] = wc;
     __syncthreads();
     uint32_t cnt = 0;
+    uint64_t rend = *o1a;
 #pragma unroll
-    for (int w = 0; w < NW; w++) cnt += rng[w];
+    for (int w = 0; w < NW; w++) { const uint32_t x = rng[w]; cnt += x; if (x) rend = omax[w]; }
     const bool single = cnt == 0;                      // record `a` alone is larger than the window
     const uint32_t b = single ? a + 1u : a + cnt;
+    ra = rend;                                         // (== offsets[rec0 + b])
     uint32_t staged;
     if (!single) {
-      uint64_t re = P.offsets[g.rec0 + b] + (wfit < wcap ? (uint64_t)kRangeSlack - 16u : 0u);
+      uint64_t re = rend + (wfit < wcap ? (uint64_t)kRangeSlack - 16u : 0u);
       if (re > P.data_len + 16u) re = P.data_len + 16u;       // (stage_window zero-fills one vector past the payload)
       stage_window<T>(P, s.win, rb16, re, tid);
       staged = (uint32_t)((re - rb16 + 15) & ~15ull);
