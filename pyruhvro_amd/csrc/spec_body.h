@@ -519,55 +519,72 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
   // itself still gets its sliding range, in its place in the order of the records (the wave counters of a wide schema are
   // scanned range by range): the tile is then [records in front of it, direct] [it, sliding] [records behind it, direct] ...
   if constexpr (SCtx<S>::kWaveCtr) {
+    // A wide schema's tile is ONE wavefront (program.h kWideTile): everything about its ranges is wave-local, and `f` has ONE
+    // call site -- with several, the walk (tens of thousands of instructions) stays a function of its own whose captured
+    // context lives in scratch memory: 38 scratch accesses per column of the 200-column workload (profiles/r06_u_*).
+    static_assert(NW == 1, "a wide schema's tile is one wavefront");
     const uint64_t tb = P.offsets[g.rec0], te = P.offsets[g.rec0 + g.nrec];
-    const uint64_t o0m = tid < g.nrec ? P.offsets[g.rec0 + tid] : 0;
+    const uint64_t o0m = tid < g.nrec ? P.offsets[g.rec0 + tid] : te;
+    const uint32_t o0lo = (uint32_t)o0m, o0hi = (uint32_t)(o0m >> 32), o1lo = (uint32_t)o1, o1hi = (uint32_t)(o1 >> 32);
+    auto lane64 = [&](uint32_t lo, uint32_t hi, int l) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, l); };
     const bool bigme = tid < g.nrec && (o1 - (o0m & ~15ull)) > (uint64_t)wfit;
-    unsigned long long* const bigw = reinterpret_cast<unsigned long long*>(rng + 16);     // [NW] giant records per wavefront (rng[NW] meanwhile: their bytes / 16)
-    const uint64_t bm = __ballot(bigme);
-    if (lane == 0) { bigw[wave] = bm; rng[wave] = 0; }
-    __syncthreads();
-    if (bigme) atomicAdd(&rng[wave], (uint32_t)((o1 - o0m) >> 4));
-    __syncthreads();
+    const uint64_t bigm = __ballot(bigme);
     uint64_t bigbytes = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) bigbytes += (uint64_t)rng[w] << 4;
-    __syncthreads();
-    // (fewer than kDirectLanes records per range on average -- bytes / window ranges for nrec records: the 200-column workload
-    //  has 11; the skewed workload's 2.5 ranges of ~100 records are better staged: 5.2 ms against 10.5 ms direct, profiles/r06_i_*)
-    if (((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap) {      // (wide schemas: short strings; a narrow schema's large records are large STRINGS, better copied out of a staged range -- skewed workload 5.2 ms against 10.7 ms)
-      const uint64_t rb16 = tb & ~15ull;
-      uint32_t a = 0;
-      while (a < g.nrec) {
-        const uint64_t wm = bigw[a >> 6] >> (a & 63u);
-        if (wm & 1ull) {                               // record `a` by itself: a sliding range
-          const uint64_t r16 = P.offsets[g.rec0 + a] & ~15ull;
-          const uint64_t left = P.data_len - r16 + 15ull;
-          const uint32_t staged = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
-          if (wave == a / 64u) {
-            stage_wave(P.data + r16, P.data_len - r16, wa, staged, lane);
-            const SlideSrc src{wa, staged, wcap, P.data + r16, P.data_len - r16, true};
-            f(src, tid == a, r16);
+    for (uint64_t m = bigm; m; m &= m - 1) { const int l = (int)__builtin_ctzll(m); bigbytes += lane64(o1lo, o1hi, l) - lane64(o0lo, o0hi, l); }
+    // (fewer than kDirectLanes records per range on average -- bytes / window ranges for nrec records: the 200-column workload has 11)
+    const bool direct = ((te - (tb & ~15ull)) - bigbytes) * (uint64_t)kDirectLanes > (uint64_t)g.nrec * wcap;
+    uint32_t a = 0;
+    while (a < g.nrec) {                               // (wave-uniform)
+      const uint64_t oa = lane64(o0lo, o0hi, (int)a);  // first byte of record `a`
+      SlideSrc src{wa, 0u, wcap, P.data, 0ull, false};
+      uint64_t rb16 = oa & ~15ull;
+      uint32_t b;
+      bool single;
+      if (direct) {
+        single = ((bigm >> a) & 1ull) != 0;
+        if (single) {
+          b = a + 1u;
+        } else {                                       // the records up to the next giant (or the end of the tile), every lane on its own
+          const uint64_t m = bigm & (~0ull << a);
+          b = m ? (uint32_t)__builtin_ctzll(m) : g.nrec;
+          rb16 = tb & ~15ull;
+          src.g = P.data + rb16; src.glim = P.data_len - rb16;
+#if defined(RH_WIDE_SCHEMA) && !defined(RH_V_NOLANES)
+          // lane windows (walk.h SlideSrc::lanes): every lane stages its own record through a slice of the window
+          const uint32_t stride = (wcap / 64u) & ~15u;
+          if (stride >= 96u) {
+            const bool mine = tid >= a && tid < b;
+            src.lanes = true; src.lwin = stride - 16u; src.lw = wa + lane * stride;
+            src.p0 = wa + (mine ? (uint32_t)((o0m & ~15ull) - rb16) : 0u);
+            if (mine) src.stage_lane();
           }
-          __syncthreads();                             // (the window is one per workgroup)
-          a += 1;
-        } else {                                       // the records up to the next giant (or the end of the tile), directly
-          uint32_t b = g.nrec;
-          for (uint32_t w = a >> 6; w < (uint32_t)NW; w++) {
-            uint64_t m = bigw[w];
-            if (w == (a >> 6)) m &= ~0ull << (a & 63u);
-            if (m) { b = w * 64u + (uint32_t)__builtin_ctzll(m); break; }
-          }
-          if (b > g.nrec) b = g.nrec;
-          const bool inr = tid >= a && tid < b;
-          if (__any(inr)) {
-            const SlideSrc src{wa, 0u, wcap, P.data + rb16, P.data_len - rb16, false};
-            f(src, inr, rb16);
-          }
-          a = b;
+#endif
+        }
+      } else {
+        const bool fitme = tid >= a && tid < g.nrec && (o1 - rb16) <= (uint64_t)wfit;      // offsets are monotonic: a prefix of [a, nrec)
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(fitme));
+        single = cnt == 0;                             // record `a` alone is larger than the window
+        b = single ? a + 1u : a + cnt;
+        if (!single) {
+          uint64_t re = lane64(o1lo, o1hi, (int)(b - 1u)) + (wfit < wcap ? (uint64_t)kRangeSlack - 16u : 0u);
+          if (re > P.data_len + 16u) re = P.data_len + 16u;       // (stage_window zero-fills one vector past the payload)
+          stage_window<T>(P, s.win, rb16, re, tid);
+          src.wlen = (uint32_t)((re - rb16 + 15) & ~15ull);
+          src.g = P.data + rb16; src.glim = P.data_len - rb16;
         }
       }
-      return;
+      if (single) {                                    // a sliding range: the window follows the record's cursor
+        const uint64_t left = P.data_len - rb16 + 15ull;
+        src.wlen = left < (uint64_t)wcap ? (uint32_t)(left & ~15ull) : wcap;
+        src.g = P.data + rb16; src.glim = P.data_len - rb16; src.sliding = true;
+        stage_wave(src.g, src.glim, wa, src.wlen, lane);
+      }
+      __syncthreads();
+      f(src, tid >= a && tid < b, rb16);
+      __syncthreads();                                 // the window is free for the next range
+      a = b;
     }
+    return;
   }
   // (a range's bounds come from the record bounds the lanes hold in registers, through LDS -- not from offsets[] again: two
   //  dependent global loads per range in front of its staging)
@@ -607,12 +624,8 @@ __device__ __forceinline__ void ranged_tile(const KParams& P, const SpecSmem<S>&
     __syncthreads();
     const bool inr = tid >= a && tid < b;
     if (__any(inr)) {
-      // a range staged whole is read like the window of a tile that fits (RangeSrc: no in-window test behind every head); wide
-      // schemas keep the one SlideSrc walk (their kernels' size and compile time: a second instance of every walk)
-      if constexpr (SCtx<S>::kWaveCtr) {
-        const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, single};
-        f(src, inr, rb16);
-      } else if (single) {
+      // a range staged whole is read like the window of a tile that fits (RangeSrc: no in-window test behind every head)
+      if (single) {
         const SlideSrc src{wa, staged, wcap, P.data + rb16, P.data_len - rb16, true};
         f(src, inr, rb16);
       } else {
@@ -712,7 +725,7 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     tflag = (uint32_t)(TF_OVER_WINDOW | TF_SUBTILED);
     lane_init_range(L, false, 0, 0, 0, 0);
     const uint32_t wa = (uint32_t)(uintptr_t)(RH_LDS uint8_t*)s.win;
-    ranged_tile<S>(P, s, g, o1, tid, [&](auto src0, bool inr, uint64_t rb16) {      // (SlideSrc, or RangeSrc for a range staged whole)
+    ranged_tile<S>(P, s, g, o1, tid, [&](auto src0, bool inr, uint64_t rb16) __attribute__((always_inline)) {      // (SlideSrc, or RangeSrc for a range staged whole)
       using SrcT = decltype(src0);
       Lane Lr;
       lane_init_range(Lr, inr, o0, o1, rb16, wa);
@@ -949,7 +962,7 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   } else {
     // the tile in ranges, as the size pass walked it (ranged_tile: same offsets, same window, same ranges)
     lane_init_range(L, false, 0, 0, 0, 0);
-    ranged_tile<S>(P, s, g, o1, tid, [&](const auto& src, bool inr, uint64_t rb16) {
+    ranged_tile<S>(P, s, g, o1, tid, [&](const auto& src, bool inr, uint64_t rb16) __attribute__((always_inline)) {      // (inlined: a walk that stays a function keeps its captured context in scratch memory)
       Lane Lr;
       lane_init_range(Lr, inr, o0, o1, rb16, wa);
       if (careful) {

@@ -253,6 +253,18 @@ __device__ __forceinline__ void stage_wave_any(const uint8_t* g, uint64_t gvalid
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// n bytes (a multiple of 16, per lane) from global memory to this lane's slice of the LDS window (SlideSrc lane windows).  A real
+// function: it is reached from every top-up hook of a wide schema's walk; its arguments travel in registers.
+__device__ __attribute__((noinline)) void stage_lane_copy(const RH_GLOBAL uint8_t* gs, uint32_t lds, uint32_t n) {
+  for (uint32_t o = 0; o < n; o += 64u) {      // four vectors in flight per round
+    v4w x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (o + 16u * k < n) x[k] = *reinterpret_cast<const RH_GLOBAL v4w*>(gs + o + 16u * k);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (o + 16u * k < n) *reinterpret_cast<RH_LDS v4w*>((uintptr_t)(lds + o + 16u * k)) = x[k];
+  }
+}
+
 // Round 6: the source of every tile that does not fit the LDS window in one piece.  Positions are LDS byte addresses like
 // LdsAbsSrc's (window byte 0 = `wa`), but only the first `wlen` bytes behind `wa` are staged: a read that is not completely
 // inside them is served from global memory at the same offset from `g` (per lane; positions in front of the window -- a lane
@@ -270,7 +282,25 @@ struct SlideSrc {
   mutable const uint8_t* g;   // global address of window byte 0 (16-byte aligned)
   mutable uint64_t glim;  // readable bytes behind g
   bool sliding;           // a single record larger than the window: refill() moves the window
-  __device__ __forceinline__ bool in(uint32_t p, uint32_t need) const { return p - wa + need <= wlen; }      // (unsigned: false in front of the window)
+#ifdef RH_WIDE_SCHEMA
+  // LANE WINDOWS (wide schemas' direct tiles, spec_body.h ranged_tile): every lane walks its own record of a kilobyte and more,
+  // too large for a range to hold many of them.  Each lane stages the next `lwin` bytes of ITS record into a slice of the window
+  // of its own (lw; slices 16 bytes apart in their bank phase) and tops it up at the hooks the generator places between the
+  // columns (h_topup) -- a record's ~400 dependent global reads become ~10 refills of 16 independent loads.  Positions stay
+  // the tile-wide coordinates of the direct walk (wa + payload offset - rb16: dense_list's table works across lanes), so a
+  // position maps to LDS through the lane's own (p0, lw), and whatever is not in the slice is read from global memory as before.
+  bool lanes = false;
+  uint32_t lwin = 0;          // bytes of a lane's slice
+  uint32_t lw = 0;            // LDS address of this lane's slice
+  mutable uint32_t p0 = 0;    // position of the slice's first byte
+  __device__ __forceinline__ uint32_t base() const { return lanes ? p0 : wa; }
+  __device__ __forceinline__ uint32_t lds(uint32_t p) const { return lanes ? p - p0 + lw : p; }
+#else
+  static constexpr bool lanes = false;
+  __device__ __forceinline__ uint32_t base() const { return wa; }
+  __device__ __forceinline__ uint32_t lds(uint32_t p) const { return p; }
+#endif
+  __device__ __forceinline__ bool in(uint32_t p, uint32_t need) const { return p - base() + need <= wlen; }      // (unsigned: false in front of the window)
   // Move the window up to the cursor of the one live lane (`owner`) once it has used half of it (called at every list
   // iteration / dense round).  Returns the distance every position has to be rebased by (0: not moved); positions noted before
   // the call (dense_list's table) must have been used up.  g / glim / wlen are per-lane copies of wave-level state, and a lane
@@ -298,6 +328,18 @@ struct SlideSrc {
   }
   template <class LaneT>
   __device__ __forceinline__ void refill(LaneT& L, uint32_t lane) const {
+#ifdef RH_WIDE_SCHEMA
+    if (lanes) {      // every live lane that has moved on: its slice from its cursor on -- when ANY lane runs low (the lanes of a wave stay in step)
+      const uint32_t off = L.cur - p0;
+      const bool low = L.live && (int32_t)(wlen - off) < (int32_t)kLaneLow;
+      if (!__any(low)) return;
+      if (L.live && off >= 16u) {
+        p0 += off & ~15u;
+        stage_lane();
+      }
+      return;
+    }
+#endif
     if (!sliding) return;
     const uint64_t lv = __ballot(L.live);
     if (lv == 0 || (lv & (lv - 1)) != 0) return;                      // (one record per sliding range: one live lane)
@@ -307,6 +349,18 @@ struct SlideSrc {
     L.cur -= delta;
     L.end -= delta;
   }
+#ifdef RH_WIDE_SCHEMA
+  static constexpr uint32_t kLaneLow = 64;      // refill when a lane has fewer staged bytes than this ahead of its cursor
+  // this lane's slice <- the lwin bytes of the payload from position p0 (whole 16-byte vectors inside the payload; what is left
+  // of a ragged end is read from global memory)
+  __device__ __forceinline__ void stage_lane() const {
+    const uint64_t goff = (uint64_t)(p0 - wa);
+    const uint64_t left = glim > goff ? glim - goff : 0ull;
+    const uint32_t n = left >= (uint64_t)lwin ? lwin : (uint32_t)(left & ~15ull);
+    stage_lane_copy(reinterpret_cast<const RH_GLOBAL uint8_t*>(reinterpret_cast<uintptr_t>(g)) + goff, lw, n);
+    wlen = n;
+  }
+#endif
   __device__ __forceinline__ GlobalSrc far(uint32_t p, uint32_t& q) const {
     // the same position as an offset from a global base that is valid for this lane: g moved forward by refills, the lane may not have
     const int64_t off = (int64_t)(int32_t)(p - wa);
@@ -315,38 +369,38 @@ struct SlideSrc {
     return GlobalSrc{g + off, off < (int64_t)glim ? (uint64_t)((int64_t)glim - off) : 0ull};
   }
   __device__ __forceinline__ uint32_t ld1(uint32_t p) const {
-    if (in(p, 1)) return LdsAbsSrc().ld1(p);
+    if (in(p, 1)) return LdsAbsSrc().ld1(lds(p));
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld1(q);
   }
   __device__ __forceinline__ uint64_t ld8(uint32_t p) const {
-    if (in(p, 12)) return LdsAbsSrc().ld8(p);
+    if (in(p, 12)) return LdsAbsSrc().ld8(lds(p));
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld8(q);
   }
   __device__ __forceinline__ uint64_t ld5(uint32_t p) const { return ld8(p); }
   __device__ __forceinline__ uint32_t ld4(uint32_t p) const {
-    if (in(p, 8)) return LdsAbsSrc().ld4(p);
+    if (in(p, 8)) return LdsAbsSrc().ld4(lds(p));
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld4(q);
   }
   __device__ __forceinline__ void ld12(uint32_t p, uint64_t& lo, uint32_t& hi) const {
-    if (in(p, 16)) { LdsAbsSrc().ld12(p, lo, hi); return; }
+    if (in(p, 16)) { LdsAbsSrc().ld12(lds(p), lo, hi); return; }
     uint32_t q; const GlobalSrc f = far(p, q); f.ld12(q, lo, hi);
   }
   __device__ __forceinline__ v4w ld16(uint32_t p) const {
-    if (in(p, 20)) return LdsAbsSrc().ld16(p);
+    if (in(p, 20)) return LdsAbsSrc().ld16(lds(p));
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld16(q);
   }
   static constexpr bool kAligned16 = true;
   __device__ __forceinline__ v4w ld16a(uint32_t p) const {      // (p 16-byte aligned -- window positions and wa are)
-    if (in(p, 16)) return LdsAbsSrc().ld16a(p);
+    if (in(p, 16)) return LdsAbsSrc().ld16a(lds(p));
     uint32_t q; const GlobalSrc f = far(p, q); return f.ld16(q);
   }
   // (copy_bytes' batched pieces: aligned dwords around p -- the same bytes through whichever side holds all of them)
   __device__ __forceinline__ uint32_t ld4a(uint32_t p) const {
-    if (in(p & ~3u, 4)) return LdsAbsSrc().ld4a(p);
+    if (in(p & ~3u, 4)) return LdsAbsSrc().ld4a(lds(p));
     uint32_t q; const GlobalSrc f = far(p & ~3u, q); return (uint32_t)f.ld8(q);
   }
   __device__ __forceinline__ void next2(uint32_t p, int j, uint32_t& d1, uint32_t& d2) const {
-    if (in((p & ~3u) + (uint32_t)j + 4u, 8)) { LdsAbsSrc().next2(p, j, d1, d2); return; }
+    if (in((p & ~3u) + (uint32_t)j + 4u, 8)) { LdsAbsSrc().next2(lds(p), j, d1, d2); return; }
     uint32_t q; const GlobalSrc f = far((p & ~3u) + (uint32_t)j + 4u, q);
     const uint64_t x = f.ld8(q);
     d1 = (uint32_t)x; d2 = (uint32_t)(x >> 32);
@@ -362,6 +416,7 @@ struct RangeSrc : LdsAbsSrc {
   static constexpr bool kSlide = true;
   static constexpr bool kMoves = false;
   static constexpr bool sliding = false;
+  static constexpr bool lanes = false;
   template <class LaneT>
   __device__ __forceinline__ void refill(LaneT&, uint32_t) const {}
   __device__ __forceinline__ uint32_t advance_to(uint32_t, uint32_t, int) const { return 0; }
@@ -375,6 +430,9 @@ struct RangeSrc : LdsAbsSrc {
 // only launches kernels built that way when every buffer of a chunk is smaller than 4 GiB.
 template <class T, bool WIDE>
 __device__ __forceinline__ void st_global(void* base, uint32_t idx, T v) {
+#ifdef RH_V_NOSTORE
+  if (reinterpret_cast<uintptr_t>(base) != 1) return;      // (timing-only build: the value is computed, never stored)
+#endif
   if (WIDE) {
     reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base))[(uint64_t)idx] = v;
   } else {
@@ -397,6 +455,9 @@ __device__ __forceinline__ void atomic_or_global(void* base, uint64_t idx, uint3
 // instruction takes the scalar-base + 32-bit-lane-offset form (no per-lane 64-bit address arithmetic).
 template <class T, bool WIDE>
 __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
+#ifdef RH_V_NOSTORE
+  if (reinterpret_cast<uintptr_t>(base) != 1) return;
+#endif
   if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off) = v;
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint32_t)off) = v;
 }
@@ -404,6 +465,9 @@ __device__ __forceinline__ void st_at(void* base, uint64_t off, T v) {
 // so it lands in the instruction's immediate offset field instead of costing a VALU add per store
 template <class T, bool WIDE, int IMM>
 __device__ __forceinline__ void st_at_imm(void* base, uint64_t off, T v) {
+#ifdef RH_V_NOSTORE
+  if (reinterpret_cast<uintptr_t>(base) != 1) return;
+#endif
   if (WIDE) *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + off + (uint64_t)IMM) = v;
   else *reinterpret_cast<RH_GLOBAL T*>(reinterpret_cast<uintptr_t>(base) + (uint64_t)(uint32_t)off + (uint64_t)IMM) = v;
 }
@@ -422,7 +486,7 @@ __device__ __forceinline__ void copy_bytes_coop(void* base, typename BufOff<WIDE
 // (RH_WIDE_SCHEMA, defined by specialize.cpp for a wide schema: copy_bytes is a real function there, called once per string
 //  column instead of inlined into every one of them -- the emit kernel of a 200-column schema compiles in 36 s instead of 88 s,
 //  for a call per column and wavefront)
-#ifdef RH_WIDE_SCHEMA
+#if defined(RH_WIDE_SCHEMA) && !defined(RH_V_INLINECOPY)
 #define RH_COPY_FN __attribute__((noinline))
 #else
 #define RH_COPY_FN __forceinline__
@@ -1107,7 +1171,7 @@ __device__ __forceinline__ void h_string(const Ctx& c, const Src& src, Lane& L, 
     if constexpr (Src::kSlide) {
       if (op.code == OP_STRING) {
         anylong = __any(act && len > 40u);
-        if (anylong) {
+        if (anylong && !src.lanes) {      // (lane windows: a long string is copied by its own lane)
           uint32_t thr;
           big = pick_long(act, len, thr);
           coop = big != 0 && len >= thr;
@@ -1302,6 +1366,12 @@ __device__ __forceinline__ void h_union_end(Lane& L) {
   L.pres = L.pstk & 1;
   L.pstk >>= 1;
   L.sstk >>= 8;
+}
+
+// Between the columns of a wide schema (specialize.cpp): a source whose window moves keeps it under the cursors (SlideSrc::refill)
+template <class Src, class Ctx>
+__device__ __forceinline__ void h_topup(const Ctx& c, const Src& src, Lane& L) {
+  if constexpr (Src::kSlide) src.refill(L, c.lane);
 }
 
 // ListDecoder / MapDecoder (+ Nullable*), 487-496, 703-770

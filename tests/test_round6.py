@@ -175,8 +175,10 @@ def test_schemas_of_any_width_compile():
 
 def test_wide_schema_kernels_compile_in_seconds(tmp_path, monkeypatch):
     """The specialised decode kernels of the 200-column schema from an EMPTY kernel cache (hiprtc, gfx950, no GPU needed): the
-    size / emit pair and the ranged pair, each kernel a compile job of its own, side by side -- ready in under 60 s on 8 vCPUs
-    (round 5: the unrolled 96-counter emit kernel alone took hiprtc 5-8 minutes)."""
+    size / emit pair and the ranged pair, each kernel a compile job of its own, side by side -- ready in about a minute on 8 vCPUs
+    (round 5: the unrolled 96-counter emit kernel alone took hiprtc 5-8 minutes).  The size / emit pair and rh_spec_size_r take
+    5-20 s; rh_spec_emit_r is the long one: 42 s while its walk was a function of its own, ~60 s since that walk is inlined
+    (its context lived in scratch memory: 1M records 12.8 -> 6.0 ms).  The bound leaves room for a slower host."""
     import subprocess
     import sys
     import time
@@ -190,7 +192,7 @@ def test_wide_schema_kernels_compile_in_seconds(tmp_path, monkeypatch):
     assert out.returncode == 0, out.stderr[-2000:]
     secs = float(out.stdout.split("secs")[1])
     ncpu = len(os.sched_getaffinity(0))
-    assert secs < (60 if ncpu >= 8 else 60 * 8 / max(ncpu, 1)), f"{secs:.1f} s on {ncpu} cpus"
+    assert secs < (100 if ncpu >= 8 else 100 * 8 / max(ncpu, 1)), f"{secs:.1f} s on {ncpu} cpus"
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 4       # size, emit, size_r, emit_r
 
 
