@@ -740,7 +740,8 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
         lane_init_range(Lr, inr, o0, o1, rb16, wa);
         const SrcT src2 = src0;            // the record again from its first byte: a window that has moved is staged anew
         if constexpr (SrcT::kMoves) {
-          if (src0.sliding && __any(src.g != src0.g)) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
+          if (src0.lanes) { if (inr) src2.stage_lane(); }      // (lane windows: every lane's slice again from its record's first byte)
+          else if (src0.sliding && __any(src.g != src0.g)) stage_wave(src0.g, src0.glim, src0.wa, src0.wlen, lane);
         }
         S::template walk<false, true>(c, src2, Lr);
       }

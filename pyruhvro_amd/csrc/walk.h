@@ -297,6 +297,7 @@ struct SlideSrc {
   __device__ __forceinline__ uint32_t lds(uint32_t p) const { return lanes ? p - p0 + lw : p; }
 #else
   static constexpr bool lanes = false;
+  __device__ __forceinline__ void stage_lane() const {}
   __device__ __forceinline__ uint32_t base() const { return wa; }
   __device__ __forceinline__ uint32_t lds(uint32_t p) const { return p; }
 #endif

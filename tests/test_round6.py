@@ -213,6 +213,41 @@ def test_wide_schemas(name, k, kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3])
+def test_wide_schema_lane_windows(k, kernel):
+    """Wide records that do not look alike: strings longer than a lane's 256-byte slice of the window and longer than the window,
+    arrays of hundreds of items (dense lists whose item lanes read another lane's record), all-null rows between 3 KB ones, a
+    record larger than the window in the middle of a direct tile, and a malformed record -- the lane windows of walk.h SlideSrc."""
+    from avrogen import synth
+    from avrogen.encoder import to_datum
+    from oracle.avro_schema import parse_schema
+    sc = parse_schema(SCHEMAS["wide97"])
+    gen = synth.GENERATORS["wide97"]
+    recs = []
+    for r in range(700):
+        v = gen(77, r)
+        if r % 7 == 0:
+            v = {key: ([] if key.startswith("a") else None) for key in v}             # a row of nulls and empty arrays
+        if r % 11 == 3:
+            v[f"c{r % 97}"] = "L" * (200 + 37 * (r % 40))                               # 200 .. 1,643 bytes: around and beyond a slice
+        if r % 53 == 5:
+            v["c50"] = "W" * 30_000                                                     # beyond the whole window
+        if r % 17 == 4:
+            v[f"a{r % 12}"] = [f"item-{r}-{j}" * (1 + j % 4) for j in range(150 + r % 200)]
+        if r == 333:
+            v["a5"] = [f"giant-{j}" for j in range(40_000)]                             # a record of its own sliding range
+        recs.append(to_datum(sc, v))
+    _check(recs, SCHEMAS["wide97"], k)
+    bad = list(recs)
+    bad[400] = bad[400][: len(bad[400]) // 2]
+    with pytest.raises(ValueError) as g:
+        P.deserialize_array_threaded(bad, SCHEMAS["wide97"], k)
+    with pytest.raises(ValueError) as e:
+        c_walker.decode_threaded(bad, SCHEMAS["wide97"], k)
+    assert str(g.value) == str(e.value)
+
+
+@pytest.mark.gpu
 def test_wide_schema_mostly_null_fits_the_window(kernel):
     """A wide schema whose columns are almost all null: small records, the tiles fit the window (the staged fast walk + wave
     counters, no ranges); and with malformed records: the reference's message, the lowest failing record."""
