@@ -67,6 +67,10 @@ sys.path.insert(0, ROOT)
 KERNEL = 0                      # rh_opts.flags: 0 auto, 1 generic interpreter, 2 schema-specialised
 STATS_EVERY = 2                 # every 2nd timed step carries the kernel timestamps (see run(); --stats-every)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# This process decodes a dozen workloads one after the other, each leaving its arenas (up to 5 GB) in the engine's device pool;
+# past the pool's default of 24 GB of idle blocks every release is a hipFree and every call a hipMalloc (the skewed workload's
+# synchronous call: 144 ms instead of 6.3).  288 GB of HBM: let the pool keep them (read when the library creates its pools).
+os.environ.setdefault("RUHVRO_HIP_DEVICE_CACHE_MB", str(96 * 1024))
 WORKLOADS = {
     # name: (generator config, records per GPU, num_chunks, description)
     "full10m": ("full", 10_000_000, 8, "10M records of the generate_avro.py schema (BASELINE.json config 4), num_chunks=8"),
