@@ -282,6 +282,29 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
     uint64_t redm[kScanSets];
     SCtx<S> cz[kScanSets] = {c, c, c, c};
     static_assert(kScanSets == 4, "cz is initialised for four sets");
+    // A list of plain strings (S::dense_str): a candidate is one length varint -- decoded by hand from unchecked window reads,
+    // the four sets' reads in flight together, instead of four passes through the string handler (its in-window tests, its
+    // validity and counter plumbing: ~3,000 cycles per 256-byte span, 380 per 28-byte item of a 2M-item array; profiles/r06_y_*).
+    // Only while the span and a head behind it lie inside the staged bytes; the handler takes the steps near the window's end.
+    bool byhand = false;
+    if constexpr (S::dense_str(LID) >= 0 && Src::kMoves) {
+      byhand = __builtin_amdgcn_readfirstlane((int)((cur_s - src.wa) + (uint32_t)(64 * kScanSets) + 8u <= src.wlen)) != 0;
+      if (byhand) {
+        uint32_t y[kScanSets];
+#pragma unroll
+        for (int h = 0; h < kScanSets; h++) y[h] = LdsAbsSrc().ld4(cur_s + (uint32_t)h * 64u + c.lane);
+#pragma unroll
+        for (int h = 0; h < kScanSets; h++) {
+          uint32_t raw, n;
+          const bool ok = varint24(y[h], 4u, raw, n);
+          const uint32_t len = raw >> 1;
+          static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; cz[h].cnt[k] = k == S::dense_str(LID) ? len : 0u; });
+          nxt[h] = (uint32_t)h * 64u + c.lane + n + len;
+          redm[h] = SIZE ? __ballot(!ok || (raw & 1u) != 0u) : 0ull;      // (a longer or a negative length: the careful walk's)
+        }
+      }
+    }
+    if (!byhand) {
 #pragma unroll
     for (int h = 0; h < kScanSets; h++) {
       static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; cz[h].cnt[k] = 0; });
@@ -295,7 +318,10 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
       nxt[h] = Lc.cur - cur_s;
       redm[h] = SIZE ? __ballot(Lc.redo) : 0ull;
     }
-    // follow the chain through the candidates
+    }
+    // follow the chain through the candidates (a branch per set: reading all four sets' answers for a hop and selecting among
+    // them with scalar selects was measured slower in the size walk -- eight and more v_readlane per hop: 1.54 -> 2.06 ms for four
+    // 9,000-item arrays -- and 9 % faster in the emit walk, profiles/r06_y_*; not kept)
     uint32_t pos = 0;
     while (pos < (uint32_t)(64 * kScanSets) && rm_s > 0 && idx_s < limit) {
       const int pl = (int)(pos & 63u), ps = (int)(pos >> 6);
