@@ -215,7 +215,7 @@ def test_wide_schemas(name, k, kernel):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 3])
 def test_wide_schema_lane_windows(k, kernel):
-    """Wide records that do not look alike: strings longer than a lane's 256-byte slice of the window and longer than the window,
+    """Wide records that do not look alike: strings longer than a lane's 192-byte slice of the window and longer than the window,
     arrays of hundreds of items (dense lists whose item lanes read another lane's record), all-null rows between 3 KB ones, a
     record larger than the window in the middle of a direct tile, and a malformed record -- the lane windows of walk.h SlideSrc."""
     from avrogen import synth
