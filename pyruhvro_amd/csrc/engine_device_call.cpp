@@ -128,7 +128,7 @@ struct rh_decode_call {
       if (sk ? launch_module(sk->emit_fn, P, nblocks, (uint32_t)tile, emit_lds, stream, ev.at(3), P.ranged ? nullptr : ev.at(4))
              : rh_launch_emit(&P, emit_lds, stream, ev.at(3), ev.at(4)))
         throw HipError("k_emit launch failed");
-      if (P.ranged && launch_module(emit_r, P, nblocks, (uint32_t)tile, emit_lds, stream, nullptr, ev.at(4))) throw HipError("k_emit (ranged) launch failed");
+      if (P.ranged && launch_module(emit_r, P, nblocks + (P.worklist ? rh::kBigFront : 0u), (uint32_t)tile, emit_lds, stream, nullptr, ev.at(4))) throw HipError("k_emit (ranged) launch failed");
     } else {
       ev.rec(3, stream);
       ev.rec(4, stream);
@@ -346,7 +346,8 @@ struct rh_decode_call {
     const uint64_t o_lcnt = align_up(o_flag + 4ull * nblocks, kAlign);
     // (per-record counters from the size pass to the emit pass: two per dword for the specialised kernels, one for the generic ones)
     const uint64_t o_lcnt32 = align_up(o_lcnt + 4ull * (sk ? (uint64_t)((cs.KL + 1) / 2) : (uint64_t)cs.KL) * nblocks * tile, kAlign);
-    const uint64_t ws_bytes = align_up(o_lcnt32 + ((size_r && emit_r) ? 4ull * (uint64_t)cs.KL * nblocks * tile : 0), kAlign);      // (+ the ranged pair's 32-bit counters)
+    const uint64_t o_wl = align_up(o_lcnt32 + ((size_r && emit_r) ? 4ull * (uint64_t)cs.KL * nblocks * tile : 0), kAlign);      // (+ the ranged pair's 32-bit counters)
+    const uint64_t ws_bytes = align_up(o_wl + ((size_r && emit_r) ? 8ull + 8ull * nblocks : 0), kAlign);                           // (+ its work list: large tiles first)
     hp.mark("setup");
     ws = Lease(dev_pool(), ws_bytes, device);
     hctrl = Lease(pin_pool(), ctrl_bytes, device);
@@ -371,6 +372,8 @@ struct rh_decode_call {
     P.tileflag = (uint32_t*)(ws.ptr() + o_flag);
     P.lanecnt = (uint32_t*)(ws.ptr() + o_lcnt);
     P.lanecnt32 = (uint32_t*)(ws.ptr() + o_lcnt32);
+    P.worklist = (P.ranged && K > 0 && n > 0) ? (uint32_t*)(ws.ptr() + o_wl) : nullptr;      // (filled by the size kernel: only with a size pass)
+    P.bigmark = P.worklist ? P.worklist + 2 + nblocks : nullptr;
 
     // LDS: fixed part + input window sized from the mean record length (falls back to global reads
     // for workgroups whose 256 records do not fit)
@@ -415,6 +418,9 @@ struct rh_decode_call {
       if (fixed_win >= 0) win = std::min<uint64_t>((uint64_t)fixed_win & ~15ull, (lds_cap - lds_fixed) & ~15ull);
     }
     P.win_bytes = (uint32_t)win;
+    // (the ranged pair takes LARGE tiles first, program.h KParams::worklist: large = well beyond both the window and this call's mean
+    //  tile -- every tile of a wide schema is several windows)
+    P.big_tile_bytes = (uint64_t)rh::kBigTileWindows * std::max<uint64_t>(win, nblocks ? payload / nblocks : 0);
     lds_bytes = lds_fixed + (uint32_t)win;
     // optional in-kernel phase timing of the specialised kernels (RUHVRO_HIP_PROFILE=1)
     static const bool profile_env = [] { const char* e = std::getenv("RUHVRO_HIP_PROFILE"); return e && *e && *e != '0'; }();
@@ -453,11 +459,13 @@ struct rh_decode_call {
     if (try_single(two_sync, ratio_hook)) return;
     timed_size = n > 0 && K > 0;
     if (timed_size) {
+      if (P.worklist) HIPCHK(hipMemsetAsync(P.worklist, 0, 8ull + 8ull * nblocks, stream));      // the list's length, every tile's mark
+
       // (with the ranged pair: the size kernel's start and the ranged size kernel's stop bracket the pass)
       if (sk ? launch_module(sk->size_fn, P, nblocks, (uint32_t)tile, lds_bytes, stream, ev.at(0), P.ranged ? nullptr : ev.at(1))
              : rh_launch_size(&P, lds_bytes, stream, ev.at(0), ev.at(1)))
         throw HipError("k_size launch failed");
-      if (P.ranged && launch_module(size_r, P, nblocks, (uint32_t)tile, lds_bytes, stream, nullptr, ev.at(1))) throw HipError("k_size (ranged) launch failed");
+      if (P.ranged && launch_module(size_r, P, nblocks + (P.worklist ? rh::kBigFront : 0u), (uint32_t)tile, lds_bytes, stream, nullptr, ev.at(1))) throw HipError("k_size (ranged) launch failed");
       if (sized) HIPCHK(hipEventRecord(sized, stream));
       // (the single-submission path scans and lays the arena out in ONE launch, below)
       if (!fused && rh_launch_scan(&P, stream, ev.at(5), ev.at(2))) throw HipError("k_scan launch failed");

@@ -229,6 +229,17 @@ struct KParams {
   uint32_t null_slots;       // null_slots_for(k): a power of two <= kNullSlots
   uint32_t ranged;           // 1: the ranged kernels (rh_spec_size_r / rh_spec_emit_r) follow the size / emit kernel of this call: those leave every tile past the window to them
   uint32_t all_careful;      // 1: no size pass classified the tiles (schemas without variable-length output): the emit kernel walks every tile carefully
+  // ranged kernels: LARGE tiles first.  A tile with a record of tens of thousands of items runs for milliseconds on one lane;
+  // met last it IS the kernel's tail.  rh_spec_size appends every tile of more than big_tile_bytes that it leaves to the
+  // ranged pair to a list -- [0] = its length (zeroed per call), [2 ..] = the tiles -- and notes its place + 1 in bigmark[tile]
+  // (zeroed per call); the pair is launched with kBigFront workgroups in FRONT of the usual ones: front workgroup b takes list
+  // entry b, the workgroup of a tile's usual place leaves it alone when a front workgroup has it.  Every other tile keeps its
+  // place (one atomic per LARGE tile: an append per tile past the window cost the size kernel 0.35 ms of same-address atomics).
+  uint32_t* worklist;
+  uint32_t* bigmark;         // [nblocks]
+  uint64_t big_tile_bytes;   // a tile of more bytes than this is LARGE: kBigTileWindows windows, and as many mean tiles of this call
 };
+constexpr uint32_t kBigTileWindows = 3;
+constexpr uint32_t kBigFront = 4096;
 
 }  // namespace rh

@@ -691,6 +691,20 @@ __device__ __forceinline__ void spec_ctx_init(SCtx<S>& c, const KParams& P, cons
 // P.ranged says that kernel follows, else walked by the fallback above).  RANGED = true: rh_spec_size_r, which only works on the
 // tiles past the window (ranged_tile) -- a code object of its own, compiled when a schema first meets such tiles, so that the
 // hot kernel's registers, code size and compile time are those of the tiles that fit.
+// The ranged kernels' tile of workgroup b (program.h KParams::worklist): the first kBigFront workgroups take the large tiles the
+// size kernel listed, the others their usual tile unless a front workgroup has it; false: no tile for this workgroup.
+__device__ __forceinline__ bool ranged_tile_of_block(const KParams& P, uint32_t b, uint32_t& tile) {
+  if (!P.worklist) { tile = tile_of_block(b, P.nblocks); return true; }
+  if (b < kBigFront) {
+    if (b >= P.worklist[0]) return false;
+    tile = P.worklist[2u + b];
+    return true;
+  }
+  tile = tile_of_block(b - kBigFront, P.nblocks);
+  const uint32_t m = P.bigmark[tile];
+  return !(m != 0u && m <= kBigFront);
+}
+
 template <class S, bool RANGED = false>
 __device__ __forceinline__ void spec_size(const KParams& P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -698,7 +712,9 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
   constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW, KP = SCtx<S>::KP;
-  const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
+  uint32_t tile = 0;
+  if constexpr (RANGED) { if (!ranged_tile_of_block(P, blockIdx.x, tile)) return; }      // (workgroup-uniform, ahead of every barrier)
+  else tile = tile_of_block(blockIdx.x, P.nblocks);
   const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
@@ -709,6 +725,13 @@ __device__ __forceinline__ void spec_size(const KParams& P) {
     // ... or nobody's: the ranged pair is not part of this call.  The call is refused (LF_NEED_RANGED: k_init / k_emit return at
     // once) and the host repeats it -- on the generic kernels, while the pair compiles; with the pair from then on.
     if (!RANGED && P.ranged == 0 && tid == 0) atomicOr(reinterpret_cast<uint32_t*>(P.first_bad) + 2, (uint32_t)LF_NEED_RANGED);
+    if constexpr (!RANGED) {
+      if (P.ranged != 0 && P.worklist && tid == 0 && (we - wb16) > P.big_tile_bytes) {      // a large tile: to the front of the ranged pair
+        const uint32_t at = atomicAdd(&P.worklist[0], 1u);
+        P.worklist[2u + at] = tile;
+        P.bigmark[tile] = at + 1u;
+      }
+    }
     return;
   }
   if (fits) stage_window<T>(P, s.win, wb16, we, tid);
@@ -862,7 +885,9 @@ __device__ __forceinline__ void spec_emit(const KParams& P) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   RH_MARK_INIT;
   constexpr int T = TileOf<S>::T, NW = TileOf<S>::NW, KP = SCtx<S>::KP;
-  const uint32_t tile = tile_of_block(blockIdx.x, P.nblocks);
+  uint32_t tile = 0;
+  if constexpr (RANGED) { if (!ranged_tile_of_block(P, blockIdx.x, tile)) return; }      // (workgroup-uniform, ahead of every barrier)
+  else tile = tile_of_block(blockIdx.x, P.nblocks);
   const Geo g = geometry<T>(P, tile);
   uint64_t o0 = 0, o1 = 0;   // this lane's record bounds: issued together with the window bounds
   if (tid < g.nrec) { o0 = P.offsets[g.rec0 + tid]; o1 = P.offsets[g.rec0 + tid + 1]; }
