@@ -19,7 +19,9 @@ if "cpu_baseline" in d:
     cb = d["cpu_baseline"]
     print("cpu", f"{cb['value']:.4g}", cb["cores"], "reference:", cb.get("reference"), {k: (round(v["value"] / 1e6, 2), round(v["wall_ms"], 3)) for k, v in cb.get("at_metric_sizes", {}).items()})
 if "other_configs" in d:
-    print({k: (round(v["ms_per_step"], 4), round(v.get("sync_call_ms", 0), 4), round(v["emit_frac"], 3), v.get("traffic")) for k, v in d["other_configs"].items()})
+    # (the 10M lines of round 6 carry kernel_ms["path"] instead of a pipelined ms_per_step)
+    print({k: (round(v.get("ms_per_step", v.get("kernel_ms", {}).get("path", 0)), 4), round(v.get("sync_call_ms", 0), 4), round(v.get("emit_frac", 0), 3),
+               v.get("traffic"), (v.get("parity_check") or {}).get("result")) for k, v in d["other_configs"].items()})
 if "end_to_end" in d:
     e = d["end_to_end"]
     print({k: (round(e[k]["value"] / 1e6, 1), round(e[k]["wall_ms"], 2)) for k in ("packed_pageable", "record_slices", "packed_8_logical_shards") if k in e})
