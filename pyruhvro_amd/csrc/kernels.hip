@@ -90,14 +90,32 @@ struct ICtx {
 // the interpreter: scalar program counter, one handler call per op
 // --------------------------------------------------------------------------
 // (round 6: the interpreter walks fast or careful like the specialised kernels -- walk.h `reject` -- instead of always careful)
+// (round 6, last session: the program is read through the CONSTANT address space -- s_load_dwordx8 + x2 on a wave-uniform pc --
+//  and the op that follows is requested before the current one runs.  Through the generic pointer of KParams the compiler fetched
+//  every op with two VECTOR loads + v_readfirstlane behind s_waitcnt vmcnt(0): a vector-L1 round trip in front of every handler,
+//  and in the emit walk -- vmcnt counts in order on this part -- a drain of every store the wavefront had in flight, once per op.)
+typedef const __attribute__((address_space(4))) Op* ProgPtr;
+__device__ __forceinline__ Op ld_op(ProgPtr p) {      // (field by field: a struct copy out of another address space does not compile on the host pass)
+  Op o;
+  o.code = p->code; o.flags = p->flags; o.dom = p->dom; o.a = p->a; o.b = p->b; o.c = p->c;
+  o.buf0 = p->buf0; o.buf1 = p->buf1; o.buf2 = p->buf2; o.node = p->node;
+  return o;
+}
 template <bool EMIT, bool CAREFUL, class Ctx, class Src>
 __device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& src, Lane& L) {
+  const ProgPtr prog = reinterpret_cast<ProgPtr>(reinterpret_cast<uintptr_t>(P.prog));
   int pc = 0;
+  Op nxt = ld_op(prog);
   for (;;) {
     pc = __builtin_amdgcn_readfirstlane(pc);
-    const Op op = P.prog[pc];
+    const Op op = nxt;
+    // (a use of every field HERE: without it the compiler sinks each field's load into the handler that reads it -- a dozen
+    //  narrow s_loads, each waited for on the spot -- instead of one s_load_dwordx8 + x2 that is in flight while the previous op runs)
+    asm volatile("" ::"s"(op.code), "s"(op.flags), "s"(op.dom), "s"(op.a), "s"(op.b), "s"(op.c), "s"(op.buf0), "s"(op.buf1), "s"(op.buf2), "s"(op.node));
+    if (op.code == OP_END) return;                          // (the last op of a program: nothing is read behind it)
+    int npc = op.code == OP_LIST_TAIL ? op.b : pc + 1;      // LIST_TAIL goes back to its LIST_NEXT
+    nxt = ld_op(prog + npc);
     switch (op.code) {
-      case OP_END: return;
       case OP_FIXED: h_fixed<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_STRING:
       case OP_ENUM: h_string<EMIT, CAREFUL>(c, src, L, op); break;
@@ -108,17 +126,14 @@ __device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& 
       case OP_UNION_END: h_union_end(L); break;
       case OP_LIST_BEGIN: h_list_begin<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_LIST_NEXT:
-        if (!h_list_next<CAREFUL, (EMIT && !CAREFUL)>(c, src, L, op)) { pc = op.b; continue; }
+        if (!h_list_next<CAREFUL, (EMIT && !CAREFUL)>(c, src, L, op)) { npc = op.b; nxt = ld_op(prog + npc); }      // no lane has an item left: to LIST_END
         break;
-      case OP_LIST_TAIL:
-        h_list_tail(c, L, op);
-        pc = op.b;
-        continue;
+      case OP_LIST_TAIL: h_list_tail(c, L, op); break;
       case OP_LIST_END: h_list_end<EMIT>(c, L, op); break;
       case OP_BIN: h_bin<EMIT, CAREFUL>(c, src, L, op); break;
       default: return;
     }
-    pc++;
+    pc = npc;
   }
 }
 
