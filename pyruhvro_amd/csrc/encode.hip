@@ -15,6 +15,15 @@
 
 namespace rh {
 
+typedef const __attribute__((address_space(4))) Op* ProgPtr;
+__device__ __forceinline__ Op ld_op(ProgPtr p) {      // (field by field: see kernels.hip)
+  Op o;
+  o.code = p->code; o.flags = p->flags; o.dom = p->dom; o.a = p->a; o.b = p->b; o.c = p->c;
+  o.buf0 = p->buf0; o.buf1 = p->buf1; o.buf2 = p->buf2; o.node = p->node;
+  return o;
+}
+
+
 struct ECtx {
   const EParams* P;
   uint32_t* idx;        // LDS [ndom][256] current row of this lane in every row domain
@@ -48,13 +57,19 @@ struct EInterp {
   template <int MODE>
   static __device__ __forceinline__ void walk(ECtx& c, ELane& L) {
     const EParams& P = *c.P;
+    // (the program through the constant address space, the next op requested while this one runs: kernels.hip `walk`)
+    const ProgPtr prog = reinterpret_cast<ProgPtr>(reinterpret_cast<uintptr_t>(P.prog));
     int pc = 0;
+    Op nxt = ld_op(prog);
     for (;;) {
       pc = __builtin_amdgcn_readfirstlane(pc);
-      const Op op = P.prog[pc];
+      const Op op = nxt;
+      asm volatile("" ::"s"(op.code), "s"(op.flags), "s"(op.dom), "s"(op.a), "s"(op.b), "s"(op.c), "s"(op.buf0), "s"(op.buf1), "s"(op.buf2), "s"(op.node));
+      if (op.code == OP_END) return;
+      int npc = op.code == OP_LIST_TAIL ? op.b : pc + 1;
+      nxt = ld_op(prog + npc);
       const bool wr = L.writes();          // this lane writes this node's bytes
       switch (op.code) {
-        case OP_END: return;
 
         case OP_FIXED: {                      // fast_encode.rs:391-399, 407-455
           if (wr) {
@@ -178,7 +193,7 @@ struct EInterp {
         }
         case OP_LIST_NEXT: {
           const bool item = L.live && L.err == 0 && c.remaining(op.c) > 0;
-          if (!__any(item)) { pc = op.b; continue; }
+          if (!__any(item)) { npc = op.b; nxt = ld_op(prog + npc); break; }
           L.pres = item;
           break;
         }
@@ -187,13 +202,12 @@ struct EInterp {
             c.remaining(op.c) -= 1;
             c.row(op.a) += 1;
           }
-          pc = op.b;
-          continue;
+          break;                               // (npc = op.b: back to LIST_NEXT)
         }
         case OP_LIST_END: e_list_end<MODE>(c, L); break;
         default: return;
       }
-      pc++;
+      pc = npc;
     }
   }
 };
