@@ -94,6 +94,39 @@ struct ICtx {
 //  and the op that follows is requested before the current one runs.  Through the generic pointer of KParams the compiler fetched
 //  every op with two VECTOR loads + v_readfirstlane behind s_waitcnt vmcnt(0): a vector-L1 round trip in front of every handler,
 //  and in the emit walk -- vmcnt counts in order on this part -- a drain of every store the wavefront had in flight, once per op.)
+// Handlers with the op's kind and its null-union bits as compile-time constants (the FAST walks only): h_fixed / h_string test
+// `op.a`, `op.code` and `op.flags` a dozen times each, and with a run-time op every test is a scalar compare + select or branch --
+// the generic kernels are bound by the CU's scalar unit (profiles/r06_s5_generic_scalar_program.txt: ~50 SALU instructions per
+// op).  The dispatch picks the instance; inside it the tests fold.
+template <int A, int NL, bool EMIT, class Ctx, class Src>      // NL: 0 = no null union, 1 = ["null", T], 2 = [T, "null"]
+__device__ __forceinline__ void h_fixed_k(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  Op o = op;
+  o.a = A;
+  o.flags = (op.flags & ~(F_NULLABLE | F_NULL_FIRST)) | (NL == 1 ? (F_NULLABLE | F_NULL_FIRST) : NL == 2 ? F_NULLABLE : 0);
+  h_fixed<EMIT, false>(c, src, L, o);
+}
+template <int CODE, int NL, bool EMIT, class Ctx, class Src>
+__device__ __forceinline__ void h_string_k(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  Op o = op;
+  o.code = CODE;
+  o.flags = (op.flags & ~(F_NULLABLE | F_NULL_FIRST)) | (NL == 1 ? (F_NULLABLE | F_NULL_FIRST) : NL == 2 ? F_NULLABLE : 0);
+  h_string<EMIT, false>(c, src, L, o);
+}
+template <int A, bool EMIT, class Ctx, class Src>
+__device__ __forceinline__ void h_fixed_nl(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  const int nl = (op.flags & F_NULLABLE) ? ((op.flags & F_NULL_FIRST) ? 1 : 2) : 0;
+  if (nl == 0) h_fixed_k<A, 0, EMIT>(c, src, L, op);
+  else if (nl == 1) h_fixed_k<A, 1, EMIT>(c, src, L, op);
+  else h_fixed_k<A, 2, EMIT>(c, src, L, op);
+}
+template <int CODE, bool EMIT, class Ctx, class Src>
+__device__ __forceinline__ void h_string_nl(const Ctx& c, const Src& src, Lane& L, const Op& op) {
+  const int nl = (op.flags & F_NULLABLE) ? ((op.flags & F_NULL_FIRST) ? 1 : 2) : 0;
+  if (nl == 0) h_string_k<CODE, 0, EMIT>(c, src, L, op);
+  else if (nl == 1) h_string_k<CODE, 1, EMIT>(c, src, L, op);
+  else h_string_k<CODE, 2, EMIT>(c, src, L, op);
+}
+
 typedef const __attribute__((address_space(4))) Op* ProgPtr;
 __device__ __forceinline__ Op ld_op(ProgPtr p) {      // (field by field: a struct copy out of another address space does not compile on the host pass)
   Op o;
@@ -116,9 +149,25 @@ __device__ __forceinline__ void walk(const KParams& P, const Ctx& c, const Src& 
     int npc = op.code == OP_LIST_TAIL ? op.b : pc + 1;      // LIST_TAIL goes back to its LIST_NEXT
     nxt = ld_op(prog + npc);
     switch (op.code) {
-      case OP_FIXED: h_fixed<EMIT, CAREFUL>(c, src, L, op); break;
+      case OP_FIXED:
+        if constexpr (CAREFUL) h_fixed<EMIT, true>(c, src, L, op);
+        else {
+          switch (op.a) {
+            case FK_I32: h_fixed_nl<FK_I32, EMIT>(c, src, L, op); break;
+            case FK_I64: h_fixed_nl<FK_I64, EMIT>(c, src, L, op); break;
+            case FK_BOOL: h_fixed_nl<FK_BOOL, EMIT>(c, src, L, op); break;
+            default: h_fixed<EMIT, false>(c, src, L, op); break;      // float / double
+          }
+        }
+        break;
       case OP_STRING:
-      case OP_ENUM: h_string<EMIT, CAREFUL>(c, src, L, op); break;
+        if constexpr (CAREFUL) h_string<EMIT, true>(c, src, L, op);
+        else h_string_nl<OP_STRING, EMIT>(c, src, L, op);
+        break;
+      case OP_ENUM:
+        if constexpr (CAREFUL) h_string<EMIT, true>(c, src, L, op);
+        else h_string_nl<OP_ENUM, EMIT>(c, src, L, op);
+        break;
       case OP_REC_BEGIN: h_rec_begin<EMIT, CAREFUL>(c, src, L, op); break;
       case OP_REC_END: h_rec_end(L); break;
       case OP_UNION_BEGIN: h_union_begin<EMIT, CAREFUL>(c, src, L, op); break;
