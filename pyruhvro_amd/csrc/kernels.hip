@@ -103,7 +103,7 @@ __device__ __forceinline__ void h_fixed_k(const Ctx& c, const Src& src, Lane& L,
   Op o = op;
   o.a = A;
   o.flags = (op.flags & ~(F_NULLABLE | F_NULL_FIRST)) | (NL == 1 ? (F_NULLABLE | F_NULL_FIRST) : NL == 2 ? F_NULLABLE : 0);
-  h_fixed<EMIT, false>(c, src, L, o);
+  h_fixed<EMIT, false>(c, src, L, o);      // (a further split on `dom == 0` in the emit walk: no gain, profiles/r06_s5_*)
 }
 template <int CODE, int NL, bool EMIT, class Ctx, class Src>
 __device__ __forceinline__ void h_string_k(const Ctx& c, const Src& src, Lane& L, const Op& op) {
