@@ -287,6 +287,7 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
     // validity and counter plumbing: ~3,000 cycles per 256-byte span, 380 per 28-byte item of a 2M-item array; profiles/r06_y_*).
     // Only while the span and a head behind it lie inside the staged bytes; the handler takes the steps near the window's end.
     bool byhand = false;
+    uint32_t padv = 0, pnn = 0;      // (by hand) a candidate's advance / length-varint bytes, one byte per set; advance 0: not a plain short item
     if constexpr (S::dense_str(LID) >= 0 && Src::kMoves) {
       byhand = __builtin_amdgcn_readfirstlane((int)((cur_s - src.wa) + (uint32_t)(64 * kScanSets) + 8u <= src.wlen)) != 0;
       if (byhand) {
@@ -301,6 +302,9 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
           static_for<0, S::KL>([&](auto ik) { constexpr int k = decltype(ik)::value; cz[h].cnt[k] = k == S::dense_str(LID) ? len : 0u; });
           nxt[h] = (uint32_t)h * 64u + c.lane + n + len;
           redm[h] = SIZE ? __ballot(!ok || (raw & 1u) != 0u) : 0ull;      // (a longer or a negative length: the careful walk's)
+          const bool plain = ok && (raw & 1u) == 0u && n + len < 256u;
+          padv |= (plain ? n + len : 0u) << (8 * h);
+          pnn |= (plain ? n : 0u) << (8 * h);
         }
       }
     }
@@ -323,6 +327,30 @@ __device__ __forceinline__ void item_scan(const SCtx<S>& c, const Src& src, Lane
     // them with scalar selects was measured slower in the size walk -- eight and more v_readlane per hop: 1.54 -> 2.06 ms for four
     // 9,000-item arrays -- and 9 % faster in the emit walk, profiles/r06_y_*; not kept)
     uint32_t pos = 0;
+    // The hops of a list of plain strings (by hand): a candidate's answer is ONE byte of a packed register -- its advance, the set
+    // picked by a shift -- so a hop is one v_readlane (two in the size walk, which also needs the bytes of the length varints: the
+    // items' string bytes are the distance hopped minus those) and a dozen scalar instructions instead of a branch per set, the
+    // anomaly masks and a counter read per hop below (~45 instructions per item: 1.54 ms per 9,000-item array and pass,
+    // profiles/r06_y_*).  A candidate that is not a plain item of fewer than 256 bytes has advance 0 and is left to the loop below.
+    if constexpr (S::dense_str(LID) >= 0 && Src::kMoves) {
+      if (byhand) {
+        uint32_t sumn = 0, hops = 0;
+        const uint32_t room = limit - idx_s;                               // (> 0: the loop around this)
+        const uint32_t left = rm_s < room ? rm_s : room;                   // hops this block and this round allow
+        while (pos < (uint32_t)(64 * kScanSets) && hops < left) {
+          const int pl = (int)(pos & 63u);
+          const uint32_t sh = (pos >> 3) & 24u;
+          const uint32_t a = ((uint32_t)__builtin_amdgcn_readlane((int)padv, pl) >> sh) & 0xFFu;
+          if (a == 0u) break;
+          if constexpr (SIZE) sumn += ((uint32_t)__builtin_amdgcn_readlane((int)pnn, pl) >> sh) & 0xFFu;
+          else { if (c.lane == 0) tab[idx_s - lo + hops] = cur_s + pos; }
+          pos += a;
+          hops++;
+        }
+        rm_s -= hops; idx_s += hops;
+        if constexpr (SIZE) acc[S::dense_str(LID)] += pos - sumn;
+      }
+    }
     while (pos < (uint32_t)(64 * kScanSets) && rm_s > 0 && idx_s < limit) {
       const int pl = (int)(pos & 63u), ps = (int)(pos >> 6);
       if constexpr (!SIZE) {
